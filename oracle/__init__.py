@@ -1,0 +1,187 @@
+"""oracle -- CPU checkers for the KNN / Chamfer / Hausdorff hot path. TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package. The product (``point_cloud_utils_amd``) never imports it and has no CPU fallback.
+
+Three checkers, strongest first:
+
+* ``ref``    -- ``oracle/_ref/libpcu_ref.so``: the reference's *own* vendored nanoflann.hpp
+               (``/root/reference/external/nanoflann/nanoflann.hpp``) compiled where it lies with the
+               reference's flags, behind a driver that restates ``src/point_cloud_distance.cpp:21-99,
+               211-225`` (``oracle/ref_shim.cpp``). Built only where ``/root/reference`` exists; the
+               built ``.so`` travels to the GPU box with the repo snapshot.
+* ``port``   -- ``oracle/libpcu_oracle.so``: a plain-C restatement of the same algorithm
+               (``oracle/kdtree_oracle.c`` + ``kdtree_body.inc``), pinned bit-exactly against ``ref`` and
+               against ``tests/golden/*.npz`` (generated from ``ref`` by ``tests/golden/make_golden.py``).
+* ``brute``  -- exact-arithmetic brute force ordered by (d2, index); equals the kd-tree result whenever
+               no exact distance tie touches the top-k (``SURVEY.md`` section 8c).
+
+The Python tails (``hausdorff_distance``, ``chamfer_distance``) restate
+``point_cloud_utils/__init__.py:52-120`` of the reference on top of whichever checker is selected.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+
+
+def build(force=False):
+    """Compile the checkers (gcc / g++ only). `_ref` is rebuilt only where /root/reference exists."""
+    port = os.path.join(_HERE, "libpcu_oracle.so")
+    if force or not os.path.exists(port) or os.path.exists("/root/reference/external/nanoflann/nanoflann.hpp") \
+            and not os.path.exists(os.path.join(_HERE, "_ref", "libpcu_ref.so")):
+        subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _load(path):
+    return ctypes.CDLL(path) if os.path.exists(path) else None
+
+
+_libs = {}
+
+
+def lib(kind):
+    if kind not in _libs:
+        if kind == "ref":
+            _libs[kind] = _load(os.path.join(_HERE, "_ref", "libpcu_ref.so"))
+        else:
+            p = os.path.join(_HERE, "libpcu_oracle.so")
+            if not os.path.exists(p):
+                build()
+            _libs[kind] = _load(p)
+    return _libs[kind]
+
+
+def have_ref():
+    return lib("ref") is not None
+
+
+def _prep(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        raise ValueError("float32/float64 only")
+    return a
+
+
+def _suffix(a):
+    return "f32" if a.dtype == np.float32 else "f64"
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def knn(query, dataset, k, squared_distances=False, max_points_per_leaf=10, num_threads=-1, kind="port",
+        timing=None):
+    """(dists (n,k), corrs (n,k) int64) exactly as shortest_distances_nanoflann fills them (no squeeze)."""
+    q, r = _prep(query), _prep(dataset)
+    assert q.dtype == r.dtype and q.ndim == 2 and r.ndim == 2 and q.shape[1] == 3 and r.shape[1] == 3
+    n = q.shape[0]
+    d = np.empty((n, k), dtype=q.dtype)
+    c = np.empty((n, k), dtype=np.int64)
+    L = lib(kind if kind != "brute" else "port")
+    if L is None:
+        raise RuntimeError(f"oracle library for kind={kind!r} is not built")
+    if kind == "ref":
+        t = (ctypes.c_double * 2)()
+        rc = getattr(L, "pcu_ref_knn_" + _suffix(q))(_ptr(q), _c_i64(n), _ptr(r), _c_i64(r.shape[0]), _c_int(k),
+                                                   _c_int(int(squared_distances)), _c_int(max_points_per_leaf),
+                                                   _c_int(num_threads), _ptr(d), _ptr(c), t)
+        if timing is not None:
+            timing["build_s"], timing["search_s"] = t[0], t[1]
+    elif kind == "port":
+        rc = getattr(L, "pcu_oracle_knn_" + _suffix(q))(_ptr(q), _c_i64(n), _ptr(r), _c_i64(r.shape[0]), _c_int(k),
+                                                      _c_int(int(squared_distances)), _c_int(max_points_per_leaf),
+                                                      _ptr(d), _ptr(c))
+    elif kind == "brute":
+        rc = getattr(L, "pcu_oracle_brute_knn_" + _suffix(q))(_ptr(q), _c_i64(n), _ptr(r), _c_i64(r.shape[0]),
+                                                            _c_int(k), _c_int(int(squared_distances)),
+                                                            _ptr(d), _ptr(c), None)
+    else:
+        raise ValueError(kind)
+    if rc != 0:
+        raise RuntimeError("oracle failed")
+    return d, c
+
+
+def brute_knn_with_ties(query, dataset, k, squared_distances=False):
+    """brute-force result + per-query flag: an exact d2 tie inside the top-(k+1)."""
+    q, r = _prep(query), _prep(dataset)
+    n = q.shape[0]
+    d = np.empty((n, k), dtype=q.dtype)
+    c = np.empty((n, k), dtype=np.int64)
+    tie = np.zeros(n, dtype=np.uint8)
+    rc = getattr(lib("port"), "pcu_oracle_brute_knn_" + _suffix(q))(_ptr(q), _c_i64(n), _ptr(r), _c_i64(r.shape[0]),
+                                                                  _c_int(k), _c_int(int(squared_distances)),
+                                                                  _ptr(d), _ptr(c), _ptr(tie))
+    assert rc == 0
+    return d, c, tie.astype(bool)
+
+
+def tree_dump(dataset, max_points_per_leaf=10):
+    """The restatement's kd-tree: (vAcc, nodes_i[n,3]=(child1,child2,divfeat), nodes_f[n,2], nodes_lr[n,2])."""
+    r = _prep(dataset)
+    m = r.shape[0]
+    cap = 2 * m + 16
+    vacc = np.empty(m, np.int64)
+    ni = np.empty((cap, 3), np.int32)
+    nf = np.empty((cap, 2), r.dtype)
+    nlr = np.empty((cap, 2), np.int64)
+    fn = getattr(lib("port"), "pcu_oracle_tree_dump_" + _suffix(r))
+    fn.restype = ctypes.c_int64
+    nn = fn(_ptr(r), _c_i64(m), _c_int(max_points_per_leaf), _ptr(vacc), _ptr(ni), _ptr(nf), _ptr(nlr), _c_i64(cap))
+    return vacc, ni[:nn], nf[:nn], nlr[:nn]
+
+
+# ---- reference API surface on top of a checker (binding + Python tails) -------------------------------
+
+def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False, max_points_per_leaf=10,
+                        num_threads=-1, kind="port"):
+    """src/point_cloud_distance.cpp:123-164 incl. the k==1 squeeze (tests/test_examples.py:363-368)."""
+    if k <= 0:
+        raise ValueError(f"Invalid value for k ({k}) must be greater than 0.")
+    d, c = knn(query_points, dataset_points, k, squared_distances, max_points_per_leaf, num_threads, kind)
+    if k == 1:
+        return d[:, 0], c[:, 0]
+    return d, c
+
+
+def one_sided_hausdorff_distance(source, target, return_index=True, squared_distances=False,
+                                 max_points_per_leaf=10, kind="port"):
+    """src/point_cloud_distance.cpp:186-234."""
+    d, c = knn(source, target, 1, squared_distances, max_points_per_leaf, 0, kind)
+    i = int(np.argmax(d[:, 0]))          # np.argmax: first maximum, like Eigen's strict '>' visitor
+    if return_index:
+        return float(d[i, 0]), i, int(c[i, 0])
+    return float(d[i, 0])
+
+
+def hausdorff_distance(x, y, return_index=False, squared_distances=False, max_points_per_leaf=10, kind="port"):
+    """point_cloud_utils/__init__.py:52-81."""
+    hxy, ix1, iy1 = one_sided_hausdorff_distance(x, y, True, squared_distances, max_points_per_leaf, kind)
+    hyx, iy2, ix2 = one_sided_hausdorff_distance(y, x, True, squared_distances, max_points_per_leaf, kind)
+    h = max(hxy, hyx)
+    if return_index and hxy > hyx:
+        return h, ix1, iy1
+    elif return_index and hxy <= hyx:
+        return h, ix2, iy2
+    return h
+
+
+def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10, kind="port"):
+    """point_cloud_utils/__init__.py:84-120."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    _, cxy = k_nearest_neighbors(x, y, 1, False, max_points_per_leaf, kind=kind)
+    _, cyx = k_nearest_neighbors(y, x, 1, False, max_points_per_leaf, kind=kind)
+    dxy = np.linalg.norm(x[cyx] - y, axis=-1, ord=p_norm).mean()
+    dyx = np.linalg.norm(y[cxy] - x, axis=-1, ord=p_norm).mean()
+    cham = np.mean(dxy) + np.mean(dyx)
+    if return_index:
+        return cham, cxy, cyx
+    return cham
