@@ -1,0 +1,284 @@
+"""point_cloud_utils_amd -- MI355X (gfx950) drop-in for point-cloud-utils' KNN / Chamfer / Hausdorff hot path.
+
+The four callables below have the signatures, defaults, dtypes, shapes and error behaviour of the reference's
+``pcu.k_nearest_neighbors`` / ``pcu.one_sided_hausdorff_distance`` (``src/point_cloud_distance.cpp:123-164``,
+``:186-234``) and ``pcu.hausdorff_distance`` / ``pcu.chamfer_distance``
+(``point_cloud_utils/__init__.py:52-81``, ``:84-120``), so
+
+    import point_cloud_utils_amd as pcu
+
+is a drop-in for that path. All computation happens in hand-written HIP kernels behind the C ABI of
+``libpcu_hip.so`` (``include/pcu_hip.h``); there is no CPU fallback: without the library or without a GPU the
+calls raise.
+
+Inputs may be numpy arrays (host; copied to the GPU for the call, results returned as numpy / Python scalars,
+exactly as the reference returns them) or, as an extension, CUDA/HIP ``torch`` tensors (device-resident: nothing
+crosses PCIe, array results are returned as ``torch`` tensors on the same device).
+
+``max_points_per_leaf`` and ``num_threads`` are kd-tree / OpenMP knobs of the reference; they are accepted for
+signature compatibility and do not influence results (the reference's results do not depend on them either,
+except for the order of exact distance ties, which follows ``max_points_per_leaf``'s tree).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Stats, set_cell_occupancy, device_count  # noqa: F401
+
+__all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_distance", "chamfer_distance",
+           "last_stats", "set_cell_occupancy", "device_count"]
+
+_last_stats = {}
+
+
+def last_stats():
+    """Statistics of the most recent call (escalations, tie handling, device milliseconds)."""
+    return dict(_last_stats)
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch") and hasattr(a, "data_ptr")
+
+
+def _shape2(a):
+    sh = tuple(a.shape)
+    if len(sh) == 2:
+        return sh
+    if len(sh) == 1:            # numpyeigen maps a 1-D array to a column vector
+        return (sh[0], 1)
+    raise ValueError(f"Invalid number of dimensions ({len(sh)}): expected a matrix of shape (n, 3).")
+
+
+def _dtype_name(a):
+    if _is_torch(a):
+        return str(a.dtype).replace("torch.", "")
+    return np.asarray(a).dtype.name
+
+
+def _check_pair(a, b, aname, bname, zero_fmt, dim_fmt):
+    """dtype / shape validation in the order of src/point_cloud_distance.cpp:136-149 (and :195-208)."""
+    da, db = _dtype_name(a), _dtype_name(b)
+    if da not in ("float32", "float64"):
+        raise ValueError(f"Invalid scalar type ({da}) for argument '{aname}'. Expected one of ['float32', 'float64'].")
+    if db != da:
+        raise ValueError(f"Invalid scalar type ({db}) for argument '{bname}'. Expected it to match argument "
+                         f"'{aname}' which is of type {da}.")
+    sa, sb = _shape2(a), _shape2(b)
+    if sa[0] == 0 or sb[0] == 0:
+        raise ValueError(zero_fmt.format(sa[0], sa[1], sb[0], sb[1]))
+    if sa[1] != 3 or sb[1] != 3:
+        raise ValueError(dim_fmt.format(sa[0], sa[1], sb[0], sb[1]))
+    return da
+
+
+_KNN_ZERO = ("Invalid input set with zero elements: query_points and dataset_points must have shape (n, 3) and (m, 3). "
+             "Got query_points.shape = ({}, {}), dataset_points.shape = ({}, {}).")
+_KNN_DIM = ("Only 3D inputs are supported: query_points and dataset_points must have shape (n, 3) and (m, 3). "
+            "Got query_points.shape = ({}, {}), dataset_points.shape = ({}, {}).")
+_HD_ZERO = ("Invalid input set with zero elements: source and targets must have shape (n, 3) and (m, 3). "
+            "Got source.shape = ({}, {}), target.shape = ({}, {}).")
+_HD_DIM = ("Only 3D inputs are supported: source and targets must have shape (n, 3) and (m, 3). "
+           "Got source.shape = ({}, {}), target.shape = ({}, {}).")
+
+
+class _Dev:
+    """Resolved inputs of one call: contiguous buffers, pointers, device, stream, flags."""
+
+    def __init__(self, a, b):
+        self.torch = _is_torch(a) or _is_torch(b)
+        if self.torch:
+            import torch
+            if not (_is_torch(a) and _is_torch(b)) or not (a.is_cuda and b.is_cuda) or a.device != b.device:
+                raise ValueError("torch inputs must both be CUDA/HIP tensors on the same device")
+            self.a, self.b = a.contiguous(), b.contiguous()
+            self.device = a.device.index if a.device.index is not None else torch.cuda.current_device()
+            self.tdev = a.device
+            self.stream = torch.cuda.current_stream(a.device).cuda_stream
+            self.flags = _lib.PTRS_ON_DEVICE
+            self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
+            self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64
+            self.t_dtype = a.dtype
+        else:
+            self.a, self.b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+            self.device = _lib.default_device()
+            self.stream = None
+            self.flags = 0
+            self.pa, self.pb = self.a.ctypes.data, self.b.ctypes.data
+            self.np_dtype = self.a.dtype.type
+        self.suffix = "f32" if self.np_dtype == np.float32 else "f64"
+        self.ctx = _lib.ctx(self.device)
+
+    def empty(self, shape, kind):
+        """kind: 'T' (input dtype) or 'i64'."""
+        if self.torch:
+            import torch
+            return torch.empty(shape, dtype=self.t_dtype if kind == "T" else torch.int64, device=self.tdev)
+        return np.empty(shape, dtype=self.np_dtype if kind == "T" else np.int64)
+
+    @staticmethod
+    def ptr(x):
+        if x is None:
+            return None
+        return x.data_ptr() if _is_torch(x) else x.ctypes.data
+
+
+def _record(st):
+    _last_stats.clear()
+    _last_stats.update(st.as_dict())
+
+
+def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False, max_points_per_leaf=10,
+                        num_threads=-1):
+    """
+    Compute the k nearest neighbors (L2 distance) from each point in the query point cloud to the dataset point cloud.
+
+    Args:
+        query_points : n by 3 array of representing a set of n points (each row is a point of dimension 3).
+        dataset_points : m by 3 array of representing a set of m points (each row is a point of dimension 3).
+        k : the number of nearest neighbors to query per point.
+        squared_distances : If set to True, then return squared L2 distances. Default is False.
+        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        num_threads : OpenMP knob of the reference; accepted and ignored.
+
+    Returns:
+        dists : An (n, k)-shaped array such that `dists[i,k]` contains the k^th shortest L2 distance from the point `query_points[i, :]` to `dataset_points`
+        corrs : An (n, k)-shaped array such that `corrs[i,k]` contains the index into `dataset_points` of the k^th nearest point to `query_points[i, :]`
+        (singleton dimensions are squeezed, as the reference's binding does: k == 1 gives (n,)-shaped results)
+    """
+    k = int(k)
+    if k <= 0:   # src/point_cloud_distance.cpp:133-135
+        raise ValueError(f"Invalid value for k ({k}) must be greater than 0.")
+    _check_pair(query_points, dataset_points, "query_points", "dataset_points", _KNN_ZERO, _KNN_DIM)
+    d = _Dev(query_points, dataset_points)
+    n, m = int(d.a.shape[0]), int(d.b.shape[0])
+    dists = d.empty((n, k), "T")
+    corrs = d.empty((n, k), "i64")
+    st = Stats()
+    flags = d.flags | (_lib.SQUARED if squared_distances else 0)
+    with _lib.lock():
+        rc = getattr(_lib.lib(), "pcu_hip_knn_" + d.suffix)(d.ctx, d.pa, n, d.pb, m, k, _Dev.ptr(dists), _Dev.ptr(corrs),
+                                                           flags, d.stream, ctypes.addressof(st))
+    _lib.check(rc)
+    _record(st)
+    # npe::move(..., squeeze): a matrix with a singleton dimension comes back 1-D
+    # (pinned for k == 1 by tests/test_examples.py:363-368 of the reference).
+    if k == 1 or n == 1:
+        return dists.reshape(-1), corrs.reshape(-1)
+    if not d.torch:
+        q = np.asarray(query_points)
+        if q.flags.f_contiguous and not q.flags.c_contiguous:      # EigenDenseLike keeps the query's storage order
+            dists = np.asfortranarray(dists)
+    return dists, corrs
+
+
+def one_sided_hausdorff_distance(source, target, return_index=True, squared_distances=False, max_points_per_leaf=10):
+    """
+    Compute the one sided Hausdorff distance from source to target
+
+    Args:
+        source : n by 3 array of representing a set of n points (each row is a point of dimension 3)
+        target : m by 3 array of representing a set of m points (each row is a point of dimension 3)
+        return_index : Optionally return the index pair `(i, j)` into source and target such that `source[i, :]` and `target[j, :]` are the two points with maximum shortest distance.
+        squared_distances : If set to True, then return squared L2 distances.
+        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+
+    Returns:
+        d : The largest shortest distance, `d` between each point in `source` and the points in `target`.
+        i, j : (if return_index) indices such that `source[i, :]` and `target[j, :]` are the two points with maximum shortest distance.
+    """
+    _check_pair(source, target, "source", "target", _HD_ZERO, _HD_DIM)
+    d = _Dev(source, target)
+    n, m = int(d.a.shape[0]), int(d.b.shape[0])
+    od = np.zeros(2, dtype=d.np_dtype)
+    oi = np.zeros(2, dtype=np.int64)
+    oj = np.zeros(2, dtype=np.int64)
+    st = Stats()
+    flags = d.flags | (_lib.SQUARED if squared_distances else 0)
+    with _lib.lock():
+        rc = getattr(_lib.lib(), "pcu_hip_one_sided_hausdorff_" + d.suffix)(
+            d.ctx, d.pa, n, d.pb, m, od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream, ctypes.addressof(st))
+    _lib.check(rc)
+    _record(st)
+    if return_index:
+        return float(od[0]), int(oi[0]), int(oj[0])
+    return float(od[0])
+
+
+def hausdorff_distance(x, y, return_index=False, squared_distances=False, max_points_per_leaf=10):
+    """
+    Compute the Hausdorff distance between x and y
+
+    Args:
+        x : n by 3 array of representing a set of n points (each row is a point of dimension 3)
+        y : m by 3 array of representing a set of m points (each row is a point of dimension 3)
+        return_index : Optionally return the index pair `(i, j)` into x and y such that `x[i, :]` and `y[j, :]` are the two points with maximum shortest distance.
+        squared_distances : If set to True, then return squared L2 distances. Default is False.
+        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+
+    Returns:
+        The largest shortest distance, `d` between each point in `source` and the points in `target`.
+        If `return_index` is set, then this function returns a tuple (d, i, j).
+    """
+    _check_pair(x, y, "source", "target", _HD_ZERO, _HD_DIM)
+    d = _Dev(x, y)
+    n, m = int(d.a.shape[0]), int(d.b.shape[0])
+    od = np.zeros(2, dtype=d.np_dtype)
+    oi = np.zeros(2, dtype=np.int64)
+    oj = np.zeros(2, dtype=np.int64)
+    st = Stats()
+    flags = d.flags | (_lib.SQUARED if squared_distances else 0)
+    with _lib.lock():   # one call: both clouds are indexed once and searched in both directions
+        rc = getattr(_lib.lib(), "pcu_hip_hausdorff_" + d.suffix)(
+            d.ctx, d.pa, n, d.pb, m, od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream, ctypes.addressof(st))
+    _lib.check(rc)
+    _record(st)
+    # point_cloud_utils/__init__.py:69-81, on Python floats exactly as there
+    hausdorff_x_to_y, idx_x1, idx_y1 = float(od[0]), int(oi[0]), int(oj[0])
+    hausdorff_y_to_x, idx_y2, idx_x2 = float(od[1]), int(oi[1]), int(oj[1])
+    hausdorff = max(hausdorff_x_to_y, hausdorff_y_to_x)
+    if return_index and hausdorff_x_to_y > hausdorff_y_to_x:
+        return hausdorff, idx_x1, idx_y1
+    elif return_index and hausdorff_x_to_y <= hausdorff_y_to_x:
+        return hausdorff, idx_x2, idx_y2
+    return hausdorff
+
+
+def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10):
+    """
+    Compute the chamfer distance between two point clouds x, and y
+
+    Args:
+        x : n by 3 array of points
+        y : m by 3 array of points
+        return_index: If set to True, will return a pair (corrs_x_to_y, corrs_y_to_x) where
+                    corrs_x_to_y[i] stores the index into y of the closest point to x[i]
+                    (i.e. y[corrs_x_to_y[i]] is the nearest neighbor to x[i] in y).
+                    corrs_y_to_x is similar to corrs_x_to_y but with x and y reversed.
+        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        p_norm : Which norm to use. p_norm can be any real number, inf (for the max norm) -inf (for the min norm),
+                0 (for sum(x != 0))
+    Returns:
+        The chamfer distance between x an dy.
+        If return_index is set, then this function returns a tuple (chamfer_dist, corrs_x_to_y, corrs_y_to_x).
+    """
+    _check_pair(x, y, "query_points", "dataset_points", _KNN_ZERO, _KNN_DIM)
+    d = _Dev(x, y)
+    n, m = int(d.a.shape[0]), int(d.b.shape[0])
+    cxy = d.empty((n,), "i64") if return_index else None
+    cyx = d.empty((m,), "i64") if return_index else None
+    means = np.zeros(2, dtype=np.float64)
+    st = Stats()
+    with _lib.lock():
+        rc = getattr(_lib.lib(), "pcu_hip_chamfer_" + d.suffix)(
+            d.ctx, d.pa, n, d.pb, m, float(p_norm), means.ctypes.data, _Dev.ptr(cxy), _Dev.ptr(cyx),
+            d.flags, d.stream, ctypes.addressof(st))
+    _lib.check(rc)
+    _record(st)
+    # __init__.py:112-115: both means are scalars of the input dtype; their sum is the result
+    dists_x_to_y = d.np_dtype(means[1])      # norm(x[corrs_y_to_x] - y).mean()
+    dists_y_to_x = d.np_dtype(means[0])      # norm(y[corrs_x_to_y] - x).mean()
+    cham_dist = np.mean(dists_x_to_y) + np.mean(dists_y_to_x)
+    if return_index:
+        return cham_dist, cxy, cyx
+    return cham_dist

@@ -1,0 +1,101 @@
+"""ctypes binding of libpcu_hip.so (C ABI in include/pcu_hip.h). No fallback: if the library is missing the
+import of any operator fails loudly; if no GPU is visible, creating a context raises RuntimeError."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcu_hip.so")
+
+PTRS_ON_DEVICE = 1
+SQUARED = 2
+NO_TIE_ORDER = 4
+
+ERR_INVALID = -1
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("n_queries", ctypes.c_int64), ("n_escalated", ctypes.c_int64), ("n_tie_flagged", ctypes.c_int64),
+                ("n_tie_true", ctypes.c_int64), ("n_passes", ctypes.c_int32), ("n_grid_builds", ctypes.c_int32),
+                ("ms_index", ctypes.c_float), ("ms_search", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("ms_tie", ctypes.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+_lock = threading.RLock()
+_ctxs = {}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). point_cloud_utils_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.pcu_hip_last_error.restype = ctypes.c_char_p
+        L.pcu_hip_version.restype = ctypes.c_char_p
+        L.pcu_hip_ctx_workspace_bytes.restype = ctypes.c_int64
+        L.pcu_hip_ctx_workspace_bytes.argtypes = [ctypes.c_void_p]
+        L.pcu_hip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.pcu_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
+        L.pcu_hip_ctx_set_cell_occupancy.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        vp, i64, ci, u = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint
+        for suf in ("f32", "f64"):
+            getattr(L, "pcu_hip_knn_" + suf).argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_one_sided_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_chamfer_" + suf).argtypes = [vp, vp, i64, vp, i64, ctypes.c_double, vp, vp, vp, u, vp, vp]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().pcu_hip_last_error().decode("utf-8", "replace")
+
+
+def device_count():
+    return int(lib().pcu_hip_device_count())
+
+
+def default_device():
+    return int(os.environ.get("PCU_HIP_DEVICE", "0"))
+
+
+def ctx(device=None):
+    """Per-device context (stream + grow-only workspace), created on first use."""
+    if device is None:
+        device = default_device()
+    with _lock:
+        c = _ctxs.get(device)
+        if c is None:
+            L = lib()
+            h = ctypes.c_void_p()
+            rc = L.pcu_hip_ctx_create(int(device), ctypes.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"point_cloud_utils_amd: cannot create a GPU context on device {device}: "
+                                   f"{last_error()} (this package has no CPU fallback)")
+            c = h
+            _ctxs[device] = c
+        return c
+
+
+def set_cell_occupancy(points_per_cell, device=None):
+    lib().pcu_hip_ctx_set_cell_occupancy(ctx(device), float(points_per_cell))
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"libpcu_hip: {msg}")
+
+
+def lock():
+    return _lock

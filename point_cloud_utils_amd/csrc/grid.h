@@ -1,0 +1,215 @@
+// csrc/grid.h -- uniform-grid index build (HBM-bound integer/byte passes; no MFMA, no LDS tiling needed).
+//
+// Replaces the role of the reference's kd-tree *build* (nanoflann.hpp:1363-1375 buildIndex / :1001-1059
+// divideTree, which pcu runs three times per call: src/point_cloud_distance.cpp:41-42) with a counting sort of
+// the cloud into x-fastest grid-cell order. The grid only decides which candidates a query evaluates; it has
+// no influence on results, which depend only on the distance arithmetic in search.h.
+//
+// Pipeline (all on one stream, no host round trip; grid shape lives in device memory):
+//   k_grid_init   1 thread      reset bbox accumulators
+//   k_bbox        grid-stride   per-wave shuffle reduce -> 6 encoded integer atomics per block
+//   k_make_grid   1 thread      bbox -> cell edge h, cell counts G (targets `occupancy` points per cell)
+//   (memset of cell counters)
+//   k_count       1 pt/lane     cell id + rank-in-cell via returning atomicAdd on the cell counter
+//   k_scan_*      3 launches    exclusive prefix sum of the counters -> cell_start
+//   k_scatter     1 pt/lane     sorted[cell_start[cell] + rank] = {x,y,z,row}
+#pragma once
+#include "pcu_types.h"
+
+namespace pcu {
+
+constexpr int kBlock = 256;
+
+template <typename T>
+__global__ void k_grid_init(GridParams<T>* gp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int j = 0; j < 3; ++j) { gp->emin[j] = ~(typename EncT<T>::type)0; gp->emax[j] = 0; }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// pts: row-major (n,3). Lane i reads 3 consecutive scalars at 3*i: a wave covers one contiguous 768 B
+// (f32) span with three strided dword loads, all of whose sectors are consumed.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bbox(const T* __restrict__ pts, int n, GridParams<T>* gp) {
+    T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
+    T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T v = pts[3 * (size_t)i + j];
+            lo[j] = v < lo[j] ? v : lo[j];
+            hi[j] = v > hi[j] ? v : hi[j];
+        }
+    }
+    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        T a = wave_min(lo[j]), b = wave_max(hi[j]);
+        if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int j = threadIdx.x;
+        T a = s_lo[0][j], b = s_hi[0][j];
+        for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
+        if (a <= b) {   // skips blocks that saw no point (and all-NaN columns)
+            atomicMin(&gp->emin[j], enc(a));
+            atomicMax(&gp->emax[j], enc(b));
+        }
+    }
+}
+
+// One thread turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
+// cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
+template <typename T>
+__global__ void k_make_grid(GridParams<T>* gp, int n, double occupancy, int max_cells) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double ext[3];
+    for (int j = 0; j < 3; ++j) {
+        T lo = dec(gp->emin[j]), hi = dec(gp->emax[j]);
+        if (!(lo <= hi)) { lo = 0; hi = 0; }      // empty / all-NaN column
+        gp->gmin[j] = lo; gp->gmax[j] = hi;
+        ext[j] = (double)hi - (double)lo;
+    }
+    double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
+    double want = (double)n / (occupancy > 0 ? occupancy : 1.0);
+    if (want > (double)max_cells) want = (double)max_cells;
+    if (want < 1.0) want = 1.0;
+    int G[3] = {1, 1, 1};
+    double h = 1.0;
+    if (emax > 0 && isfinite(emax)) {
+        // active axes: extent not negligible against the largest one
+        bool act[3]; int nd = 0; double vol = 1.0;
+        for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
+        h = pow(vol / want, 1.0 / nd);
+        for (int it = 0; it < 200; ++it) {
+            double cells = 1.0;
+            for (int j = 0; j < 3; ++j) {
+                double g = act[j] ? floor(ext[j] / h) + 1.0 : 1.0;
+                if (g > 2048.0) g = 2048.0;                    // keeps row tables and int math small
+                G[j] = (int)g; cells *= g;
+            }
+            if (cells <= (double)max_cells) break;
+            h *= 1.05;
+        }
+        // a capped axis (2048) must still span its extent
+        for (int j = 0; j < 3; ++j) if (act[j] && h * G[j] < ext[j]) h = ext[j] / G[j] * 1.0000001;
+    }
+    gp->h = (T)h;
+    gp->inv_h = (T)1 / gp->h;
+    for (int j = 0; j < 3; ++j) {
+        gp->G[j] = G[j];
+        double scale = fabs((double)gp->gmin[j]) + fabs((double)gp->gmax[j]) + (double)G[j] * h;
+        gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
+    }
+    gp->ncells = G[0] * G[1] * G[2];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp,
+                                                  unsigned* __restrict__ cell_of, unsigned* __restrict__ rank,
+                                                  unsigned* counts) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const T x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    const int cx = cell_coord(x, gp->gmin[0], gp->inv_h, gp->G[0]);
+    const int cy = cell_coord(y, gp->gmin[1], gp->inv_h, gp->G[1]);
+    const int cz = cell_coord(z, gp->gmin[2], gp->inv_h, gp->G[2]);
+    const unsigned c = (unsigned)((cz * gp->G[1] + cy) * gp->G[0] + cx);
+    cell_of[i] = c;
+    rank[i] = atomicAdd(&counts[c], 1u);
+}
+
+// ---- exclusive scan over `counts[0..m)` in place; counts[m] receives the total -------------------------
+constexpr int kScanItems = 8;                       // per thread
+constexpr int kScanChunk = kBlock * kScanItems;     // per block
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* total) {
+    __shared__ unsigned s_w[kBlock / 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { unsigned t = s_w[w]; s_w[w] = run; run += t; }
+        s_w[kBlock / 64] = run;
+    }
+    __syncthreads();
+    unsigned ex = inc - v + s_w[wave];
+    *total = s_w[kBlock / 64];
+    __syncthreads();
+    return ex;
+}
+
+// m is read from device memory (gp->ncells) so no host round trip is needed between build stages.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ counts, const GridParams<T>* __restrict__ gp,
+                                                        unsigned* __restrict__ block_sums) {
+    const int m = gp->ncells;
+    const int base = blockIdx.x * kScanChunk;
+    if (base >= m) { if (threadIdx.x == 0) block_sums[blockIdx.x] = 0; return; }
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { int i = base + j * kBlock + threadIdx.x; if (i < m) s += counts[i]; }
+    unsigned total; block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_spine(unsigned* block_sums, int nb) {
+    unsigned carry = 0;
+    for (int base = 0; base < nb; base += kBlock) {
+        int i = base + threadIdx.x;
+        unsigned v = i < nb ? block_sums[i] : 0, total;
+        unsigned ex = block_exclusive_scan(v, &total);
+        if (i < nb) block_sums[i] = ex + carry;
+        carry += total;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* counts, const GridParams<T>* __restrict__ gp,
+                                                       const unsigned* __restrict__ block_sums, unsigned n_total) {
+    const int m = gp->ncells;
+    const int base = blockIdx.x * kScanChunk;
+    if (base >= m) return;
+    // thread-contiguous items so the running sum within a thread is the scan order
+    unsigned v[kScanItems], s = 0;
+    const int i0 = base + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { v[j] = (i0 + j < m) ? counts[i0 + j] : 0; s += v[j]; }
+    unsigned total;
+    unsigned ex = block_exclusive_scan(s, &total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { if (i0 + j < m) counts[i0 + j] = ex; ex += v[j]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[m] = n_total;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, int n, const unsigned* __restrict__ cell_of,
+                                                    const unsigned* __restrict__ rank, const unsigned* __restrict__ cell_start,
+                                                    Pt4<T>* __restrict__ sorted) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Pt4<T> p;
+    p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; p.idx = i;
+    sorted[cell_start[cell_of[i]] + rank[i]] = p;
+}
+
+}  // namespace pcu

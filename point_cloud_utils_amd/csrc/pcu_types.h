@@ -1,0 +1,63 @@
+// csrc/pcu_types.h -- device-side data layout shared by the grid-index and search kernels.
+//
+// HBM layout of one "grid index" (uniform grid over a point cloud, one per cloud per call):
+//   GridParams<T>           1 struct   bbox, cell edge, cell counts (written by k_make_grid, read by everyone
+//                                      through the scalar cache: it is wave-uniform)
+//   cell_start[ncells+1]    uint32     exclusive prefix sum of per-cell point counts, x-fastest cell order
+//   sorted[n]               Pt4<T>     the cloud permuted into cell order, AoS {x,y,z,original row}: one
+//                                      16-byte (f32) / 32-byte (f64) record per point so that a lane fetches a
+//                                      whole candidate with a single dwordx4 (two for f64) load
+// Scratch while building: cell_of[n] (uint32), rank[n] (uint32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+namespace pcu {
+
+template <typename T> struct Pt4;
+template <> struct alignas(16) Pt4<float>  { float x, y, z; int idx; };
+template <> struct alignas(32) Pt4<double> { double x, y, z; long long idx; };
+
+template <typename T> struct Limits;
+template <> struct Limits<float>  { static constexpr float  max_v = FLT_MAX; static constexpr float  eps = FLT_EPSILON; };
+template <> struct Limits<double> { static constexpr double max_v = DBL_MAX; static constexpr double eps = DBL_EPSILON; };
+
+// Order-preserving float -> unsigned encoding, so that bbox min/max can use integer atomics.
+__device__ __forceinline__ unsigned int enc(float f) {
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ unsigned long long enc(double f) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(f);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec(unsigned long long u) {
+    return __longlong_as_double((long long)((u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+template <typename T> struct EncT;
+template <> struct EncT<float>  { using type = unsigned int; };
+template <> struct EncT<double> { using type = unsigned long long; };
+
+template <typename T>
+struct GridParams {
+    T gmin[3], gmax[3];       // exact data bounding box
+    T h, inv_h;               // cell edge (same in x,y,z) and fl(1/h)
+    T slack[3];               // conservative slack on cell-face positions (certification, see search.h)
+    int G[3];                 // cells per axis
+    int ncells;               // G[0]*G[1]*G[2]
+    typename EncT<T>::type emin[3], emax[3];   // atomic bbox accumulators (encoded)
+};
+
+// Cell coordinate of value v along one axis. Separate subtract and multiply (the TU is built with
+// -ffp-contract=off); NaN maps to cell 0; values on/after the last face are clamped into the last cell.
+template <typename T>
+__device__ __forceinline__ int cell_coord(T v, T gmin, T inv_h, int G) {
+    T t = (v - gmin) * inv_h;
+    return (t >= (T)0) ? ((t < (T)G) ? (int)t : G - 1) : 0;
+}
+
+}  // namespace pcu

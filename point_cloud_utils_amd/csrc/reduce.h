@@ -1,0 +1,110 @@
+// csrc/reduce.h -- epilogues over the per-query nearest-neighbour results.
+//
+//   Hausdorff  (src/point_cloud_distance.cpp:221-225): arg-max of the per-source distance array with Eigen's
+//              maxCoeff rule -- strict '>' while visiting rows in order, i.e. the FIRST row attaining the maximum.
+//   Chamfer    (point_cloud_utils/__init__.py:112-115): mean over queries of || nn(q) - q ||_p.
+// Both are deterministic two-stage reductions (per-block partials, then one block), fp64 accumulation for sums.
+#pragma once
+#include "pcu_types.h"
+#include "grid.h"
+
+namespace pcu {
+
+constexpr int kRedBlocks = 1024;
+
+template <typename T>
+__device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long long i2) {
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+// d[n]: nearest-neighbour distance per source row (already sqrt'ed unless squared was requested).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_argmax_partial(const T* __restrict__ d, int n, T* pv, long long* pi) {
+    T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) argmax_combine(v, idx, d[i], (long long)i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
+        argmax_combine(v, idx, v2, i2);
+    }
+    __shared__ T sv[kBlock / 64]; __shared__ long long si[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);
+        pv[blockIdx.x] = v; pi[blockIdx.x] = idx;
+    }
+}
+
+// out3 = {bits of max value (as T in the first sizeof(T) bytes), i, j}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_argmax_final(const T* __restrict__ pv, const long long* __restrict__ pi, int nb,
+                                                         const long long* __restrict__ corr, T* out_v, long long* out_ij) {
+    T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
+    for (int i = threadIdx.x; i < nb; i += kBlock) argmax_combine(v, idx, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
+        argmax_combine(v, idx, v2, i2);
+    }
+    __shared__ T sv[kBlock / 64]; __shared__ long long si[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);
+        *out_v = v; out_ij[0] = idx; out_ij[1] = corr[idx];
+    }
+}
+
+__device__ __forceinline__ double block_sum(double s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ss[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) for (int w = 0; w < kBlock / 64; ++w) r += ss[w];
+    return r;   // valid in thread 0
+}
+
+// p-norm codes (numpy.linalg.norm vector ord): 2, 1, +inf, -inf, 0, other
+enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
+
+// partial[b] = sum over the block's queries of || tgt[corr[i]] - src[i] ||_p  (fp64 accumulation).
+// For p == 2 with `d` given (non-squared nn distances) the already computed distances are summed instead:
+// they are the same numbers, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) (numpy's norm(ord=2, axis=-1) squares,
+// add-reduces in axis order and takes sqrt, in the input dtype).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pnorm_partial(const T* __restrict__ src, const T* __restrict__ tgt,
+                                                          const long long* __restrict__ corr, const T* __restrict__ d,
+                                                          int n, int pcode, double p, double* partial) {
+    double s = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        T v;
+        if (pcode == P_TWO && d) {
+            v = d[i];
+        } else {
+            const long long c = corr[i];
+            const T a = tgt[3 * c] - src[3 * (size_t)i], b = tgt[3 * c + 1] - src[3 * (size_t)i + 1], e = tgt[3 * c + 2] - src[3 * (size_t)i + 2];
+            const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
+            if (pcode == P_TWO) v = sqrt(((a * a) + (b * b)) + (e * e));
+            else if (pcode == P_ONE) v = (aa + ab) + ae;
+            else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; }
+            else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; }
+            else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));
+            else v = (T)pow((double)(T)((T)pow((double)aa, p) + (T)pow((double)ab, p)) + (double)(T)pow((double)ae, p), 1.0 / p);
+        }
+        s += (double)v;
+    }
+    double r = block_sum(s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_final(const double* __restrict__ partial, int nb, double* out) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) s += partial[i];
+    double r = block_sum(s);
+    if (threadIdx.x == 0) *out = r;
+}
+
+}  // namespace pcu

@@ -1,0 +1,201 @@
+// csrc/search.h -- exact k-nearest-neighbour search over a grid index (the hot loop).
+//
+// Replaces nanoflann's per-query tree descent (nanoflann.hpp:1393-1418 findNeighbors, :1544-1624 searchLevel,
+// :194-227 KNNResultSet::addPoint) as driven by src/point_cloud_distance.cpp:49-95.
+//
+// One lane = one query, processed in the *query cloud's own cell order* so that the 64 lanes of a wave look at
+// the same few rows of dataset cells (L1/L2-resident). A lane scans the (2R+1)^3 block of cells around its
+// own cell, row by row: the cells [x0..x1] of one (y,z) row are one contiguous run of `sorted` records.
+//
+// Arithmetic contract (bit parity with the reference):
+//   d2 = ((dx*dx) + (dy*dy)) + (dz*dz),  dx = q.x - r.x, ...   all in T, no FMA (TU built with
+//   -ffp-contract=off), i.e. L2_Simple_Adaptor::evalMetric, nanoflann.hpp:496-507.
+//
+// Exactness: after the scan the lane knows its k best d2 inside the scanned box of cells. Every unscanned
+// dataset point lies beyond one of the box faces that are interior to the grid; `face_lower_bound` computes,
+// with the same rounding-monotone arithmetic, a value LB such that the *computed* d2 of any such point is
+// >= LB. The result is final ("certified") iff kth_best < LB (strict: a tie with an unscanned point is not
+// accepted). Uncertified queries are appended to `unresolved` and re-run by the host loop with a larger R or a
+// coarser grid until the scanned box is the whole grid (LB = +inf).
+//
+// Ties: MODE_FAST only *detects* that an exact tie may matter (equal d2 met at the k-th boundary, or equal
+// neighbours in the final list) and appends the query to `ties`; MODE_LEX re-runs those queries with the total
+// order (d2, dataset row) and K >= k+1 slots, and reports which of them have a genuine tie inside the
+// top-(k+1) (`true_ties`), for which the order of the reference is defined by its kd-tree traversal
+// (see tie_order.h).
+#pragma once
+#include "pcu_types.h"
+
+namespace pcu {
+
+enum { MODE_FAST = 0, MODE_LEX = 1 };
+
+template <typename T>
+struct SearchArgs {
+    const GridParams<T>* gp;        // dataset grid
+    const Pt4<T>* ref;              // dataset in cell order
+    const unsigned* cell_start;     // [ncells+1]
+    const Pt4<T>* qsorted;          // queries in their own cell order
+    const int* qlist;               // nullable: positions into qsorted to process (escalation / tie passes)
+    const int* qcount_dev;          // nullable: device-side count for qlist passes
+    int nq;                         // number of work items when qcount_dev is null
+    int R;                          // search radius in cells
+    int kreq;                       // neighbours requested (<= K)
+    int squared;                    // write d2 instead of sqrt(d2)
+    T* out_d;                       // (nq_total, kreq), original query order
+    long long* out_i;               // (nq_total, kreq)
+    int* unresolved; int* n_unresolved;
+    int* ties;       int* n_ties;         // MODE_FAST: possible tie; MODE_LEX: genuine tie ("true_ties")
+};
+
+// Append `value` for lanes with `flag` set; one atomic per wave.
+__device__ __forceinline__ void wave_append(bool flag, int value, int* list, int* counter) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+// Lower bound on the computed d2 of every dataset point whose cell lies outside [c0..c1] (per axis) of the grid.
+template <typename T>
+__device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy, T qz,
+                                              int x0, int x1, int y0, int y1, int z0, int z1) {
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    const T q[3] = {qx, qy, qz};
+    const int c0[3] = {x0, y0, z0}, c1[3] = {x1, y1, z1};
+    // distance from q to the data bbox along each axis (0 inside): valid for *every* dataset point
+    T o[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        T a = g.gmin[j] - q[j], b = q[j] - g.gmax[j];
+        T m = a > b ? a : b;
+        o[j] = m > (T)0 ? m * shrink : (T)0;
+    }
+    T lb = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (c0[j] > 0) {              // points with cell_j <= c0-1: coordinate < gmin + c0*h (+slack)
+            T B = g.gmin[j] + (T)c0[j] * g.h + g.slack[j];
+            T m = q[j] - B;
+            m = m > (T)0 ? m * shrink : (T)0;
+            m = m > o[j] ? m : o[j];
+            T t0 = j == 0 ? m : o[0], t1 = j == 1 ? m : o[1], t2 = j == 2 ? m : o[2];
+            T f = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
+            lb = f < lb ? f : lb;
+        }
+        if (c1[j] < g.G[j] - 1) {     // points with cell_j >= c1+1: coordinate >= gmin + (c1+1)*h (-slack)
+            T B = g.gmin[j] + (T)(c1[j] + 1) * g.h - g.slack[j];
+            T m = B - q[j];
+            m = m > (T)0 ? m * shrink : (T)0;
+            m = m > o[j] ? m : o[j];
+            T t0 = j == 0 ? m : o[0], t1 = j == 1 ? m : o[1], t2 = j == 2 ? m : o[2];
+            T f = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
+            lb = f < lb ? f : lb;
+        }
+    }
+    return lb;
+}
+
+template <typename T, int K, int MODE>
+__global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    if (t >= nq) return;
+    const int qpos = a.qlist ? a.qlist[t] : t;
+    const Pt4<T> q = a.qsorted[qpos];
+    const GridParams<T>& g = *a.gp;
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int R = a.R;
+
+    const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
+    const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
+    const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+    const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
+    const int y0 = max(ccy - R, 0), y1 = min(ccy + R, Gy - 1);
+    const int z0 = max(ccz - R, 0), z1 = min(ccz + R, Gz - 1);
+
+    T bd[K];
+    int bi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
+    bool tie = false;
+
+    // centre-out over rows: near rows first so the k-th best shrinks early (fewer insertions for K > 1)
+    for (int iz = 0; iz <= 2 * R; ++iz) {
+        const int cz = ccz + ((iz & 1) ? -((iz + 1) >> 1) : (iz >> 1));
+        if (cz < z0 || cz > z1) continue;
+        for (int iy = 0; iy <= 2 * R; ++iy) {
+            const int cy = ccy + ((iy & 1) ? -((iy + 1) >> 1) : (iy >> 1));
+            if (cy < y0 || cy > y1) continue;
+            const int row = (cz * Gy + cy) * Gx;
+            const unsigned s = a.cell_start[row + x0], e = a.cell_start[row + x1 + 1];
+            for (unsigned p = s; p < e; ++p) {
+                const Pt4<T> r = a.ref[p];
+                const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
+                const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                const int id = (int)r.idx;
+                if (MODE == MODE_FAST) {
+                    if (d < bd[K - 1]) {
+                        const T ev = bd[K - 1];
+#pragma unroll
+                        for (int i = K - 1; i > 0; --i) {
+                            const bool gm = bd[i - 1] > d;
+                            const bool gi = bd[i] > d;
+                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                        }
+                        if (bd[0] > d || K == 1) { bd[0] = d; bi[0] = id; }
+                        if (K > 1 && ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;   // evicted one equals the new k-th
+                    } else if (d == bd[K - 1]) {
+                        tie = true;                                                       // rejected one equals the k-th
+                    }
+                } else {
+                    const bool lt_last = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+                    if (lt_last) {
+#pragma unroll
+                        for (int i = K - 1; i > 0; --i) {
+                            const bool gm = bd[i - 1] > d || (bd[i - 1] == d && bi[i - 1] > id);
+                            const bool gi = bd[i] > d || (bd[i] == d && bi[i] > id);
+                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                        }
+                        if (K == 1 || bd[0] > d || (bd[0] == d && bi[0] > id)) { bd[0] = d; bi[0] = id; }
+                    }
+                }
+            }
+        }
+    }
+
+    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const int kreq = a.kreq;
+    T kth = bd[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) if (i == kreq - 1) kth = bd[i];
+    const bool certified = kth < lb;
+
+    if (certified) {
+        const size_t o = (size_t)q.idx * (size_t)kreq;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (i < kreq) {
+                const bool found = bi[i] != 0x7fffffff;
+                a.out_i[o + i] = found ? (long long)bi[i] : -1ll;
+                a.out_d[o + i] = found ? (a.squared ? bd[i] : sqrt(bd[i])) : (T)-1;
+            }
+        }
+        // equal neighbours inside the first kreq(+1) slots
+        bool adj = false;
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+            if (i <= kreq && bd[i] == bd[i - 1] && bi[i] != 0x7fffffff) adj = true;
+        if (MODE == MODE_FAST) tie = tie || adj; else tie = adj;
+    }
+    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
+    wave_append(certified && tie, qpos, a.ties, a.n_ties);
+}
+
+}  // namespace pcu

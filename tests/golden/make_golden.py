@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the reference's own nanoflann (oracle/_ref/libpcu_ref.so, compiled in place
+from /root/reference/external/nanoflann/nanoflann.hpp). Run where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+Each fixture stores small seeded inputs and the reference outputs (distances as raw bits via exact float arrays).
+The reference ships no golden vectors for this path, so these are generated from the reference code."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+REF_DATA = "/root/reference/data"
+
+
+def main():
+    oracle.build()
+    assert oracle.have_ref(), "needs /root/reference (oracle/_ref)"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import read_ply_vertices
+    rng = np.random.default_rng(20250321)
+    cases = {}
+
+    def add(name, q, r, k, squared=False):
+        d, c = oracle.knn(q, r, k, squared_distances=squared, kind="ref")
+        cases[name] = dict(q=q, r=r, k=np.int64(k), squared=np.int64(squared), d=d, c=c)
+
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        add(f"uniform_k1_{tag}", rng.random((1500, 3), dtype=dt), rng.random((1200, 3), dtype=dt), 1)
+        add(f"uniform_k5_{tag}", rng.random((800, 3), dtype=dt), rng.random((900, 3), dtype=dt), 5, squared=True)
+        add(f"uniform_k16_{tag}", rng.random((600, 3), dtype=dt), rng.random((1000, 3), dtype=dt), 16)
+        add(f"k_gt_m_{tag}", rng.random((50, 3), dtype=dt), rng.random((7, 3), dtype=dt), 10)
+        add(f"single_ref_{tag}", rng.random((40, 3), dtype=dt), rng.random((1, 3), dtype=dt), 1)
+        base = rng.random((700, 3), dtype=dt)
+        add(f"duplicates_k1_{tag}", rng.random((500, 3), dtype=dt), np.concatenate([base, base]), 1)
+        add(f"duplicates_k4_{tag}", rng.random((500, 3), dtype=dt), np.concatenate([base, base]), 4)
+        add(f"self_k3_{tag}", base[:400], base[:400], 3)
+        g = np.stack(np.meshgrid(*[np.arange(9)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(dt)
+        add(f"lattice_k7_{tag}", (rng.integers(0, 18, (400, 3)) / 2).astype(dt), g, 7)
+        add(f"far_queries_{tag}", (rng.random((300, 3), dtype=dt) * dt(0.1) + dt(5.0)), rng.random((900, 3), dtype=dt), 2)
+        add(f"planar_{tag}", rng.random((500, 3), dtype=dt) * np.array([1, 1, 0], dt), rng.random((800, 3), dtype=dt) * np.array([1, 1, 0], dt), 3)
+    bunny = read_ply_vertices(os.path.join(REF_DATA, "bunny.ply"))
+    dup = read_ply_vertices(os.path.join(REF_DATA, "bunny_duplicates.ply"))
+    add("bunny_vs_dup_f32", bunny.astype(np.float32)[::3], dup.astype(np.float32), 2)
+    add("dup_self_f64", dup.astype(np.float64)[::2], dup.astype(np.float64), 3)
+
+    for name, c in cases.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)
+    # Hausdorff / Chamfer scalars on a pair of the fixtures
+    out = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        a = rng.random((1000, 3), dtype=dt); b = rng.random((500, 3), dtype=dt)
+        h = oracle.hausdorff_distance(a, b, return_index=True, kind="ref")
+        o1 = oracle.one_sided_hausdorff_distance(a, b, kind="ref")
+        o2 = oracle.one_sided_hausdorff_distance(b, a, squared_distances=True, kind="ref")
+        ch, cxy, cyx = oracle.chamfer_distance(a, b, return_index=True, kind="ref")
+        ch1 = oracle.chamfer_distance(a, b, p_norm=1, kind="ref")
+        chinf = oracle.chamfer_distance(a, b, p_norm=np.inf, kind="ref")
+        ch3 = oracle.chamfer_distance(a, b, p_norm=3, kind="ref")
+        out[f"a_{tag}"] = a; out[f"b_{tag}"] = b
+        out[f"hausdorff_{tag}"] = np.array([h[0], h[1], h[2]], dtype=np.float64)
+        out[f"one_sided_ab_{tag}"] = np.array(o1, dtype=np.float64)
+        out[f"one_sided_ba_sq_{tag}"] = np.array(o2, dtype=np.float64)
+        out[f"chamfer_{tag}"] = np.array([ch, ch1, chinf, ch3], dtype=np.float64)
+        out[f"cxy_{tag}"] = cxy; out[f"cyx_{tag}"] = cyx
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+    print("wrote", len(cases) + 1, "fixtures")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/pcu_hip.h declares; host-side
+validation mirrors the reference's ValueErrors; no compute is attempted without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pcu_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcu_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from point_cloud_utils_amd import _lib
+    L = _lib.lib()
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), f"libpcu_hip.so does not export {n}"
+    assert b"gfx950" in L.pcu_hip_version()
+
+
+def test_stats_struct_size_matches_header():
+    from point_cloud_utils_amd import _lib
+    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 4 * 4
+
+
+def test_validation_errors_match_reference_texts():
+    import point_cloud_utils_amd as pcu
+    a = np.random.rand(10, 3); b = np.random.rand(5, 3)
+    with pytest.raises(ValueError, match=r"Invalid value for k \(0\) must be greater than 0\."):
+        pcu.k_nearest_neighbors(a, b, 0)
+    with pytest.raises(ValueError, match="Invalid input set with zero elements: query_points and dataset_points"):
+        pcu.k_nearest_neighbors(np.zeros((0, 3)), b, 1)
+    with pytest.raises(ValueError, match=r"Only 3D inputs are supported.*dataset_points.shape = \(5, 2\)"):
+        pcu.k_nearest_neighbors(a, np.random.rand(5, 2), 1)
+    with pytest.raises(ValueError, match="Invalid input set with zero elements: source and targets"):
+        pcu.one_sided_hausdorff_distance(a, np.zeros((0, 3)))
+    with pytest.raises(ValueError, match="Only 3D inputs are supported: source and targets"):
+        pcu.hausdorff_distance(np.random.rand(4, 4), b)
+    with pytest.raises(ValueError, match="Invalid scalar type"):
+        pcu.k_nearest_neighbors(a.astype(np.float32), b, 1)          # dtype mismatch (npe_matches)
+    with pytest.raises(ValueError, match="Invalid scalar type"):
+        pcu.chamfer_distance(a.astype(np.int32), b.astype(np.int32))
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must raise, not compute on the CPU."""
+    import point_cloud_utils_amd as pcu
+    from point_cloud_utils_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pcu.k_nearest_neighbors(np.random.rand(10, 3), np.random.rand(5, 3), 1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "point_cloud_utils_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libpcu_oracle" not in txt and "libpcu_ref" not in txt, f

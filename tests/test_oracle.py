@@ -1,0 +1,74 @@
+"""CPU tests: the oracle (plain-C restatement) against the golden vectors generated from the reference's own
+nanoflann, against oracle/_ref when present, and against exact brute force."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import cloud
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("metrics.npz"))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_port_matches_golden(path):
+    g = np.load(path)
+    d, c = oracle.knn(g["q"], g["r"], int(g["k"]), squared_distances=bool(g["squared"]), kind="port")
+    assert np.array_equal(c, g["c"])
+    assert np.array_equal(d.view(np.uint8), g["d"].view(np.uint8))   # bit-exact distances
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("leaf", [1, 10, 37])
+def test_port_matches_ref_when_present(dtype, leaf):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built on this box")
+    q, r = cloud(1, 3000, dtype), cloud(2, 2500, dtype)
+    r = np.concatenate([r, r[:500]])      # duplicates: tie order depends on the tree
+    for k in (1, 6):
+        d0, c0 = oracle.knn(q, r, k, max_points_per_leaf=leaf, kind="ref")
+        d1, c1 = oracle.knn(q, r, k, max_points_per_leaf=leaf, kind="port")
+        assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_port_matches_brute_without_ties(dtype):
+    q, r = cloud(3, 1500, dtype), cloud(4, 2000, dtype)
+    for k in (1, 9):
+        d0, c0, tie = oracle.brute_knn_with_ties(q, r, k)
+        d1, c1 = oracle.knn(q, r, k, kind="port")
+        ok = ~tie
+        assert ok.sum() > 1400
+        assert np.array_equal(c0[ok], c1[ok]) and np.array_equal(d0[ok], d1[ok])
+        assert np.array_equal(d0, d1)         # distances are unique even under ties
+
+
+def test_metrics_golden():
+    g = np.load(os.path.join(GOLD, "metrics.npz"))
+    for tag in ("f32", "f64"):
+        a, b = g[f"a_{tag}"], g[f"b_{tag}"]
+        h = oracle.hausdorff_distance(a, b, return_index=True, kind="port")
+        assert list(g[f"hausdorff_{tag}"]) == [h[0], h[1], h[2]]
+        assert tuple(g[f"one_sided_ab_{tag}"]) == oracle.one_sided_hausdorff_distance(a, b, kind="port")
+        assert tuple(g[f"one_sided_ba_sq_{tag}"]) == oracle.one_sided_hausdorff_distance(b, a, squared_distances=True, kind="port")
+        ch, cxy, cyx = oracle.chamfer_distance(a, b, return_index=True, kind="port")
+        assert float(ch) == g[f"chamfer_{tag}"][0]
+        assert np.array_equal(cxy, g[f"cxy_{tag}"]) and np.array_equal(cyx, g[f"cyx_{tag}"])
+
+
+def test_reference_test_knn_body_on_oracle():
+    """tests/test_examples.py:349-396 of the reference, with the oracle standing in for pcu."""
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        a, b = rng.random((1000, 3)), rng.random((500, 3))
+        k = int(rng.integers(10)) + 1
+        d, c = oracle.k_nearest_neighbors(a, b, k)
+        assert d.shape == ((1000, k) if k > 1 else (1000,))
+        if k == 1:
+            d, c = d[:, None], c[:, None]
+        assert np.all(np.abs(np.linalg.norm(a[:, None, :] - b[c], axis=-1) - d) < 1e-5)
+    with pytest.raises(ValueError):
+        oracle.k_nearest_neighbors(a, b, 0)
