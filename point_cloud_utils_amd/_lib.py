@@ -18,7 +18,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("n_queries", ctypes.c_int64), ("n_escalated", ctypes.c_int64), ("n_tie_flagged", ctypes.c_int64),
                 ("n_tie_true", ctypes.c_int64), ("n_passes", ctypes.c_int32), ("n_grid_builds", ctypes.c_int32),
                 ("ms_index", ctypes.c_float), ("ms_search", ctypes.c_float), ("ms_total", ctypes.c_float),
-                ("ms_tie", ctypes.c_float)]
+                ("ms_tie", ctypes.c_float), ("ms_kernel_search", ctypes.c_float),
+                ("n_kernel_search", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

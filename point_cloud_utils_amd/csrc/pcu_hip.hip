@@ -39,6 +39,8 @@ struct pcu_hip_ctx {
     std::vector<void*> extra;                 // overflow allocations of the current call
     size_t extra_bytes = 0;
     hipEvent_t ev[8] = {};
+    hipEvent_t kev[8] = {};                    // brackets of the main (pass-0) search launches of a call
+    int n_kev = 0;
     double occupancy = 0;                      // <=0: default
     int* h_pinned = nullptr;                   // small pinned readback buffer
 };
@@ -72,7 +74,17 @@ static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
         c->arena_cap = cap;
     }
     c->arena_off = 0;
+    c->n_kev = 0;
     return 0;
+}
+// Sum of the bracketed main-search kernel durations of this call (valid after the final stream sync).
+static void collect_kernel_times(pcu_hip_ctx* c, pcu_hip_stats* st) {
+    if (!st) return;
+    st->ms_kernel_search = 0; st->n_kernel_search = 0;
+    for (int i = 0; i + 1 < c->n_kev; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->kev[i], c->kev[i + 1]) == hipSuccess) { st->ms_kernel_search += ms; st->n_kernel_search++; }
+    }
 }
 static void ctx_end(pcu_hip_ctx* c) {
     for (void* p : c->extra) (void)hipFree(p);
@@ -193,7 +205,10 @@ static int knn_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const GridIndex<
         a.qlist = cur_list; a.qcount_dev = nullptr; a.nq = cur_count; a.R = R; a.kreq = k; a.squared = squared ? 1 : 0;
         a.out_d = d_out_d; a.out_i = d_out_i;
         a.unresolved = next_list; a.n_unresolved = sc.counters + 0; a.ties = sc.ties; a.n_ties = sc.counters + 1;
+        const bool time_it = st && pass == 0 && c->n_kev + 2 <= 8;
+        if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
         if (launch_search<T, MODE_FAST>(KF, a, cur_count, s)) return -1;
+        if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
         if (!have_gp) { HIP_TRY(hipMemcpyAsync(&h_gp, ridx.gp, sizeof h_gp, hipMemcpyDeviceToHost, s)); }
         HIP_TRY(hipMemcpyAsync(c->h_pinned, sc.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -301,7 +316,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
             HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
-        if (st) { st->n_queries = nq; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 2); }
+        if (st) { st->n_queries = nq; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 2); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -386,7 +401,7 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
         HIP_TRY(hipStreamSynchronize(s));
         const int nres = two_sided ? 2 : 1;
         for (int r = 0; r < nres; ++r) { out_d[r] = hv[r]; out_i[r] = hij[2 * r]; out_j[r] = hij[2 * r + 1]; }
-        if (st) { st->n_queries = two_sided ? nx + ny : nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); }
+        if (st) { st->n_queries = two_sided ? nx + ny : nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -436,7 +451,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         HIP_TRY(hipStreamSynchronize(s));
         out_mean2[0] = hs[0] / (double)nx;
         out_mean2[1] = hs[1] / (double)ny;
-        if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); }
+        if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -464,6 +479,7 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
     *out_ctx = c;
     return 0;
@@ -475,6 +491,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     ctx_end(c);
     if (c->arena) (void)hipFree(c->arena);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

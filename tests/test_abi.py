@@ -28,7 +28,7 @@ def test_header_symbols_exported():
 
 def test_stats_struct_size_matches_header():
     from point_cloud_utils_amd import _lib
-    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 4 * 4
+    assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 4 * 4 + 4 + 4
 
 
 def test_validation_errors_match_reference_texts():

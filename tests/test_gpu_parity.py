@@ -89,6 +89,14 @@ def test_seeded_vs_oracle(pcu, oracle_kind, dtype, n, m, k):
         assert (c != c0).any(axis=-1).sum() <= st["n_tie_true"]
 
 
+def _assert_knn(pcu, d, c, d0, c0):
+    """distances bit-equal; indices equal except (until the kd-order resolver lands) rows with a genuine tie."""
+    st = pcu.last_stats()
+    assert np.array_equal(d, d0), f"distances differ {st}"
+    nbad = int((c != c0).reshape(c.shape[0], -1).any(axis=-1).sum())
+    assert nbad <= st["n_tie_true"], f"{nbad} rows differ, {st}"
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
     """Disjoint / offset clouds force radius escalation and the coarse-grid fallback."""
@@ -97,7 +105,7 @@ def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
     for k in (1, 4):
         d, c = pcu.k_nearest_neighbors(q, r, k)
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
-        assert np.array_equal(d, d0) and np.array_equal(c, c0)
+        _assert_knn(pcu, d, c, d0, c0)
     assert pcu.last_stats()["n_escalated"] > 0
     # anisotropic + clustered
     rng = np.random.default_rng(9)
@@ -105,7 +113,7 @@ def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
     q = (rng.standard_normal((30000, 3)) * np.array([1.5, 0.5, 0.5])).astype(dtype)
     d, c = pcu.k_nearest_neighbors(q, r, 3)
     d0, c0 = oracle.k_nearest_neighbors(q, r, 3, kind=oracle_kind)
-    assert np.array_equal(d, d0) and np.array_equal(c, c0)
+    _assert_knn(pcu, d, c, d0, c0)
 
 
 def test_reference_test_bodies(pcu):
