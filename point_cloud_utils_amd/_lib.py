@@ -30,6 +30,29 @@ _lock = threading.RLock()
 _ctxs = {}
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7)
+    and look it up by the unversioned name, so if /opt/rocm's copy were loaded first a later `import torch` would
+    load a second runtime and find no GPU. When torch is installed (and not yet imported) its copy is therefore
+    loaded first; libpcu_hip.so's NEEDED libamdhip64.so.7 then binds to it, and so does torch later."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -37,6 +60,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). point_cloud_utils_amd has no CPU fallback.")
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         L.pcu_hip_last_error.restype = ctypes.c_char_p
         L.pcu_hip_version.restype = ctypes.c_char_p

@@ -6,12 +6,10 @@
 // no influence on results, which depend only on the distance arithmetic in search.h.
 //
 // Pipeline (all on one stream, no host round trip; grid shape lives in device memory):
-//   k_grid_init   1 thread      reset bbox accumulators
-//   k_bbox        grid-stride   per-wave shuffle reduce -> 6 encoded integer atomics per block
-//   k_make_grid   1 thread      bbox -> cell edge h, cell counts G (targets `occupancy` points per cell)
-//   (memset of cell counters)
+//   k_bbox_partial 256 blocks   per-block bbox partials (shuffle reduce, no atomics) + zero-fill of the cell counters
+//   k_make_grid    1 block      fold partials; bbox -> cell edge h, cell counts G (targets `occupancy` points per cell)
 //   k_count       1 pt/lane     cell id + rank-in-cell via returning atomicAdd on the cell counter
-//   k_scan_*      3 launches    exclusive prefix sum of the counters -> cell_start
+//   k_scan_*      2 launches    exclusive prefix sum of the counters -> cell_start
 //   k_scatter     1 pt/lane     sorted[cell_start[cell] + rank] = {x,y,z,row}
 #pragma once
 #include "pcu_types.h"
@@ -19,13 +17,6 @@
 namespace pcu {
 
 constexpr int kBlock = 256;
-
-template <typename T>
-__global__ void k_grid_init(GridParams<T>* gp) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int j = 0; j < 3; ++j) { gp->emin[j] = ~(typename EncT<T>::type)0; gp->emax[j] = 0; }
-    }
-}
 
 template <typename T>
 __device__ __forceinline__ T wave_min(T v) {
@@ -40,10 +31,15 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+constexpr int kBboxBlocks = 256;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz
+
 // pts: row-major (n,3). Lane i reads 3 consecutive scalars at 3*i: a wave covers one contiguous 768 B
-// (f32) span with three strided dword loads, all of whose sectors are consumed.
+// (f32) span with three strided dword loads, all of whose sectors are consumed. No atomics: every block
+// writes one partial; k_make_grid folds the kBboxBlocks partials. The same launch zero-fills the cell
+// counters (so the build needs no separate memset launch).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_bbox(const T* __restrict__ pts, int n, GridParams<T>* gp) {
+__global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ pts, int n, T* __restrict__ partial,
+                                                         unsigned* __restrict__ counts, int n_counts) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -54,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const T* __restrict__ pts, int 
             hi[j] = v > hi[j] ? v : hi[j];
         }
     }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_counts; i += gridDim.x * kBlock) counts[i] = 0u;
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -66,22 +63,40 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const T* __restrict__ pts, int 
         const int j = threadIdx.x;
         T a = s_lo[0][j], b = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
-        if (a <= b) {   // skips blocks that saw no point (and all-NaN columns)
-            atomicMin(&gp->emin[j], enc(a));
-            atomicMax(&gp->emax[j], enc(b));
-        }
+        partial[blockIdx.x * 6 + j] = a;
+        partial[blockIdx.x * 6 + 3 + j] = b;
     }
 }
 
-// One thread turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
+// One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
 template <typename T>
-__global__ void k_make_grid(GridParams<T>* gp, int n, double occupancy, int max_cells) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T* __restrict__ partial, int nparts,
+                                                      int n, double occupancy, int max_cells) {
+    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    {
+        T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
+        T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+        for (int b = threadIdx.x; b < nparts; b += kBlock)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                T a = partial[b * 6 + j], c = partial[b * 6 + 3 + j];
+                lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
+            }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T a = wave_min(lo[j]), c = wave_max(hi[j]);
+            if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = c; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double ext[3];
     for (int j = 0; j < 3; ++j) {
-        T lo = dec(gp->emin[j]), hi = dec(gp->emax[j]);
-        if (!(lo <= hi)) { lo = 0; hi = 0; }      // empty / all-NaN column
+        T lo = s_lo[0][j], hi = s_hi[0][j];
+        for (int w = 1; w < kBlock / 64; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
+        if (!(lo <= hi)) { lo = 0; hi = 0; }      // all-NaN column
         gp->gmin[j] = lo; gp->gmax[j] = hi;
         ext[j] = (double)hi - (double)lo;
     }
@@ -172,17 +187,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restri
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_spine(unsigned* block_sums, int nb) {
-    unsigned carry = 0;
-    for (int base = 0; base < nb; base += kBlock) {
-        int i = base + threadIdx.x;
-        unsigned v = i < nb ? block_sums[i] : 0, total;
-        unsigned ex = block_exclusive_scan(v, &total);
-        if (i < nb) block_sums[i] = ex + carry;
-        carry += total;
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* counts, const GridParams<T>* __restrict__ gp,
                                                        const unsigned* __restrict__ block_sums, unsigned n_total) {
@@ -194,8 +198,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* counts, const G
     const int i0 = base + threadIdx.x * kScanItems;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) { v[j] = (i0 + j < m) ? counts[i0 + j] : 0; s += v[j]; }
-    unsigned total;
-    unsigned ex = block_exclusive_scan(s, &total) + block_sums[blockIdx.x];
+    // offset of this chunk = sum of the totals of all earlier chunks (a few hundred values: folded here
+    // rather than by a separate single-block "spine" launch)
+    unsigned pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) pre += block_sums[b];
+    unsigned total, ptotal;
+    block_exclusive_scan(pre, &ptotal);
+    unsigned ex = block_exclusive_scan(s, &total) + ptotal;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) { if (i0 + j < m) counts[i0 + j] = ex; ex += v[j]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[m] = n_total;

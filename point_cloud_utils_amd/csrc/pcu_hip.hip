@@ -98,6 +98,7 @@ struct GridIndex {
     unsigned* cell_start = nullptr;       // counts, scanned in place
     Pt4<T>* sorted = nullptr;
     unsigned* cell_of = nullptr; unsigned* rank = nullptr; unsigned* block_sums = nullptr;
+    T* bbox_partial = nullptr;
     int n = 0, max_cells = 0, scan_blocks = 0;
 };
 
@@ -110,7 +111,7 @@ template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
     return align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1) * 4, 256) + align_up((size_t)n * sizeof(Pt4<T>), 256) +
-           2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256);
+           2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
 }
 template <typename T>
 static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ) {
@@ -121,20 +122,18 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ) {
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
+    if (aalloc(a, &g.bbox_partial, (size_t)kBboxBlocks * 6)) return -1;
     return 0;
 }
-// Enqueue the whole build on `s` (no host synchronisation).
+// Enqueue the whole build on `s`: 6 launches, no memset, no host synchronisation.
 template <typename T>
 static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s) {
     const int n = g.n;
     const int nb = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_grid_init<T>, dim3(1), dim3(64), 0, s, g.gp);
-    hipLaunchKernelGGL(k_bbox<T>, dim3(std::min(nb, 2048)), dim3(kBlock), 0, s, d_pts, n, g.gp);
-    hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(64), 0, s, g.gp, n, occ, g.max_cells);
-    HIP_TRY(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * 4, s));
+    hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.max_cells + 1);
+    hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells);
     hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
     hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(kBlock), 0, s, g.block_sums, g.scan_blocks);
     hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
     hipLaunchKernelGGL(k_scatter<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.cell_of, g.rank, g.cell_start, g.sorted);
     HIP_TRY(hipGetLastError());
@@ -148,102 +147,151 @@ static double default_occupancy(int k) {
     if (k <= 1) return 1.5;
     return std::max(2.0, (k + 3.0 * sqrt((double)k)) / 5.9);
 }
+static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+constexpr int kMaxK = 64;           // lane-per-query slots; the wave kernel uses up to 128 (k+1 rounded up)
+constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
-template <typename T, int MODE>
-static int launch_search(int K, const SearchArgs<T>& a, int nwork_upper, hipStream_t s) {
-    if (nwork_upper <= 0) return 0;
-    dim3 grid((nwork_upper + kBlock - 1) / kBlock), block(kBlock);
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK, MODE>), grid, block, 0, s, a); break;
+template <typename T>
+static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s) {
+    if (nwork <= 0) return 0;
+    dim3 grid((nwork + kBlock - 1) / kBlock), block(kBlock);
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK, MODE_FAST>), grid, block, 0, s, a); break;
     switch (K) {
-        PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
+        PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
     }
 #undef PCU_CASE
     HIP_TRY(hipGetLastError());
     return 0;
 }
-static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
-
-constexpr int kMaxK = 64;       // FAST slots; LEX uses up to 128 (k+1 rounded up)
-
 template <typename T>
-struct SearchScratch {
-    int* list_a = nullptr; int* list_b = nullptr; int* ties = nullptr; int* true_ties = nullptr;
-    int* counters = nullptr;     // [0]=unresolved [1]=ties [2]=true ties [3]=spare
-};
-template <typename T>
-static size_t scratch_bytes(int64_t nq) { return 4 * align_up((size_t)nq * 4, 256) + 256; }
-template <typename T>
-static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq) {
-    if (aalloc(a, &sc.list_a, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.list_b, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.ties, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.true_ties, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.counters, 16)) return -1;
+static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s) {
+    dim3 grid(kWaveBlocks), block(kBlock);
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a); break;
+    switch (K) {
+        PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
+        default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
+    }
+#undef PCU_CASE
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// All-queries exact KNN of `qidx`'s cloud against `ridx`'s cloud. d_ref_pts is needed only if a coarser
-// dataset grid has to be built for far-away queries. Results land in d_out_d / d_out_i in original query order.
+// Per-direction lists and counters. Counter slots:
+enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_N = 8 };
 template <typename T>
-static int knn_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const GridIndex<T>& qidx, const GridIndex<T>& ridx0,
-                      const T* d_ref_pts, double occ0, int k, bool squared, T* d_out_d, long long* d_out_i,
-                      SearchScratch<T>& sc, pcu_hip_stats* st) {
-    const int nq = qidx.n;
-    const int KF = pow2_at_least(k), KL = pow2_at_least(k + 1);
-    GridIndex<T> ridx = ridx0;
-    double occ = occ0;
-    int R = 1;
-    int* cur_list = nullptr; int cur_count = nq;
-    int* next_list = sc.list_a;
-    GridParams<T> h_gp;
-    bool have_gp = false;
-    for (int pass = 0; pass < 64; ++pass) {
-        HIP_TRY(hipMemsetAsync(sc.counters, 0, 16 * sizeof(int), s));
-        SearchArgs<T> a;
-        a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = qidx.sorted;
-        a.qlist = cur_list; a.qcount_dev = nullptr; a.nq = cur_count; a.R = R; a.kreq = k; a.squared = squared ? 1 : 0;
-        a.out_d = d_out_d; a.out_i = d_out_i;
-        a.unresolved = next_list; a.n_unresolved = sc.counters + 0; a.ties = sc.ties; a.n_ties = sc.counters + 1;
-        const bool time_it = st && pass == 0 && c->n_kev + 2 <= 8;
-        if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
-        if (launch_search<T, MODE_FAST>(KF, a, cur_count, s)) return -1;
-        if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
-        if (!have_gp) { HIP_TRY(hipMemcpyAsync(&h_gp, ridx.gp, sizeof h_gp, hipMemcpyDeviceToHost, s)); }
-        HIP_TRY(hipMemcpyAsync(c->h_pinned, sc.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        have_gp = true;
-        const int n_unres = c->h_pinned[0], n_ties = c->h_pinned[1];
-        if (st) { st->n_passes++; st->n_tie_flagged += n_ties; if (pass == 0) st->n_escalated += n_unres; }
-        if (n_ties > 0) {
-            // same grid, same radius, total order (d2,row); certification is identical so nothing is lost
-            SearchArgs<T> b = a;
-            b.qlist = sc.ties; b.nq = n_ties;
-            b.unresolved = sc.true_ties /*unused sink*/; b.n_unresolved = sc.counters + 3;
-            b.ties = sc.true_ties; b.n_ties = sc.counters + 2;
-            if (launch_search<T, MODE_LEX>(KL, b, n_ties, s)) return -1;
-            HIP_TRY(hipMemcpyAsync(c->h_pinned, sc.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (st) { st->n_passes++; st->n_tie_true += c->h_pinned[2]; }
-        }
-        if (n_unres == 0) return 0;
-        // escalate: wider radius on the same grid, then a coarser grid
-        cur_list = next_list; cur_count = n_unres;
-        next_list = (cur_list == sc.list_a) ? sc.list_b : sc.list_a;
-        const int gmax = std::max(h_gp.G[0], std::max(h_gp.G[1], h_gp.G[2]));
+struct SearchScratch {
+    int *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *t1 = nullptr, *tt = nullptr;
+    int* counters = nullptr;
+    int nq = 0;
+};
+template <typename T>
+static size_t scratch_bytes(int64_t nq) { return 5 * align_up((size_t)nq * 4, 256) + 256; }
+template <typename T>
+static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq) {
+    sc.nq = (int)nq;
+    if (aalloc(a, &sc.u1, (size_t)nq) || aalloc(a, &sc.u2, (size_t)nq) || aalloc(a, &sc.u3, (size_t)nq)) return -1;
+    if (aalloc(a, &sc.t1, (size_t)nq) || aalloc(a, &sc.tt, (size_t)nq)) return -1;
+    if (aalloc(a, &sc.counters, C_N)) return -1;
+    return 0;
+}
+
+template <typename T>
+struct SearchJob {           // one direction: queries of `qidx` against the dataset `ridx`
+    GridIndex<T> qidx, ridx;
+    const T* d_ref_pts = nullptr;
+    double occ = 1.5;
+    int k = 1; bool squared = false;
+    T* out_d = nullptr; long long* out_i = nullptr;
+    SearchScratch<T> sc;
+};
+
+template <typename T>
+static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) {
+    SearchArgs<T> a;
+    a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted;
+    a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
+    a.out_d = j.out_d; a.out_i = j.out_i;
+    a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
+    return a;
+}
+
+// Enqueue (no host sync): lane-per-query pass at R=1 over all queries, then three wave-per-query passes fed
+// by device-side lists: possible ties at R=1, stragglers at R=2, their stragglers at R=4.
+template <typename T>
+static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st) {
+    const SearchScratch<T>& sc = j.sc;
+    const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
+    HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
+    SearchArgs<T> a = base_args(j, j.ridx);
+    a.nq = j.qidx.n; a.R = 1;
+    a.unresolved = sc.u1; a.n_unresolved = sc.counters + C_U1; a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
+    const bool time_it = st && c->n_kev + 2 <= 8;
+    if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
+    if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
+    if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+    SearchArgs<T> b = base_args(j, j.ridx);
+    b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;                 // possible ties -> total order
+    b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2; b.ties = sc.tt; b.n_ties = sc.counters + C_TT;
+    if (launch_search_wave<T>(KL, b, s)) return -1;
+    b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;                 // stragglers, radius 2
+    if (launch_search_wave<T>(KL, b, s)) return -1;
+    b.qlist = sc.u2; b.qcount_dev = sc.counters + C_U2; b.R = 4;                 // radius 4
+    b.unresolved = sc.u3; b.n_unresolved = sc.counters + C_U3;
+    if (launch_search_wave<T>(KL, b, s)) return -1;
+    if (st) st->n_passes += 4;
+    return 0;
+}
+
+// After a stream sync: read the counters; finish whatever is still unresolved with coarser dataset grids
+// (host-driven, one sync per pass; only far-away / isolated queries ever get here).
+// Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, <0 on error.
+template <typename T>
+static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st) {
+    int hc[C_N];
+    HIP_TRY(hipMemcpyAsync(hc, j.sc.counters, sizeof hc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
+    int n_left = hc[C_U3];
+    if (n_left == 0) { if (st) st->n_tie_true += hc[C_TT]; return 0; }
+    const int KL = std::max(2, pow2_at_least(j.k + 1));
+    int* cur = j.sc.u3; int* nxt = j.sc.u1;
+    double occ = j.occ;
+    GridIndex<T> ridx = j.ridx;
+    GridParams<T> hg;
+    HIP_TRY(hipMemcpy(&hg, ridx.gp, sizeof hg, hipMemcpyDeviceToHost));
+    int R = 4;                                            // already done on the fine grid
+    for (int pass = 0; pass < 64 && n_left > 0; ++pass) {
+        const int gmax = std::max(hg.G[0], std::max(hg.G[1], hg.G[2]));
         if (R >= gmax) return fail(PCU_HIP_ERR_RUNTIME, "internal: search did not certify with the whole grid scanned");
-        if (R < 4 || gmax <= 8) {
-            R *= 2;
-        } else {
-            occ *= 512.0;                                   // cell edge x8
+        if (R >= 4 && gmax > 8) {                         // coarser dataset grid: cell edge x8, restart at R=1
+            occ *= 512.0;
             GridIndex<T> coarse;
             if (index_alloc(ar, coarse, ridx.n, occ)) return -1;
-            if (index_build(coarse, d_ref_pts, occ, s)) return -1;
+            if (index_build(coarse, j.d_ref_pts, occ, s)) return -1;
             if (st) st->n_grid_builds++;
-            ridx = coarse; R = 1; have_gp = false;
+            ridx = coarse; R = 1;
+            HIP_TRY(hipMemcpyAsync(&hg, ridx.gp, sizeof hg, hipMemcpyDeviceToHost, s));
+        } else {
+            R *= 2;
         }
+        HIP_TRY(hipMemsetAsync(j.sc.counters + C_SPARE, 0, sizeof(int), s));
+        SearchArgs<T> b = base_args(j, ridx);
+        b.qlist = cur; b.nq = n_left; b.R = R;
+        b.unresolved = nxt; b.n_unresolved = j.sc.counters + C_SPARE; b.ties = j.sc.tt; b.n_ties = j.sc.counters + C_TT;
+        if (launch_search_wave<T>(KL, b, s)) return -1;
+        int left = 0;
+        HIP_TRY(hipMemcpyAsync(&left, j.sc.counters + C_SPARE, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (st) st->n_passes++;
+        n_left = left;
+        int* done = cur; cur = nxt; nxt = (done == j.sc.u3) ? j.sc.u2 : done;
     }
-    return fail(PCU_HIP_ERR_RUNTIME, "internal: too many search passes");
+    if (n_left > 0) return fail(PCU_HIP_ERR_RUNTIME, "internal: too many search passes");
+    int tt = 0;
+    HIP_TRY(hipMemcpy(&tt, j.sc.counters + C_TT, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) st->n_tie_true += tt;
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------------------ validation
@@ -287,7 +335,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     if (st) memset(st, 0, sizeof *st);
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k);
     const double occ_q = 2.0;
-    size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 4096;
+    size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192;
     if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + align_up((size_t)nr * 3 * sizeof(T), 256) +
                          align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);
     if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
@@ -300,16 +348,19 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = stage_in(ar, dataset, nr, on_dev, s, &dr))) break;
         T* dd = out_d; long long* di = (long long*)out_i;
         if (!on_dev) { if ((rc = aalloc(ar, &dd, (size_t)nq * k))) break; if ((rc = aalloc(ar, &di, (size_t)nq * k))) break; }
-        GridIndex<T> ri, qi; SearchScratch<T> sc;
-        if ((rc = index_alloc(ar, ri, nr, occ))) break;
-        if ((rc = index_alloc(ar, qi, nq, occ_q))) break;
-        if ((rc = scratch_alloc(ar, sc, nq))) break;
+        SearchJob<T> job;
+        if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
+        if ((rc = index_alloc(ar, job.qidx, nq, occ_q))) break;
+        if ((rc = scratch_alloc(ar, job.sc, nq))) break;
+        job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared; job.out_d = dd; job.out_i = di;
         tm.mark(0);
-        if ((rc = index_build(ri, dr, occ, s))) break;
-        if ((rc = index_build(qi, dq, occ_q, s))) break;
+        if ((rc = index_build(job.ridx, dr, occ, s))) break;
+        if ((rc = index_build(job.qidx, dq, occ_q, s))) break;
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
-        if ((rc = knn_device(c, ar, s, qi, ri, dr, occ, k, squared, dd, di, sc, st))) break;
+        if ((rc = search_enqueue(c, s, job, st))) break;
+        if ((rc = search_finish(c, ar, s, job, st)) < 0) break;
+        rc = 0;
         tm.mark(2);
         if (!on_dev) {
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
@@ -323,56 +374,71 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
 }
 
 // ------------------------------------------------------------------------------------------------ two-sided ops
-// Shared front end of hausdorff / chamfer: both clouds indexed once; x->y and y->x searches with k = 1.
+// Shared front end of hausdorff / chamfer: both clouds indexed once; x->y and y->x searches with k = 1, both
+// enqueued back to back (each direction owns its lists and counters), epilogues enqueued behind them, ONE
+// stream synchronisation for the whole call unless some query needs the host-driven coarse-grid loop.
 template <typename T>
 struct PairState {
     const T *dx = nullptr, *dy = nullptr;
-    GridIndex<T> ix, iy;
-    T *d_xy = nullptr, *d_yx = nullptr;                 // nn distance of each x row in y / each y row in x
-    long long *c_xy = nullptr, *c_yx = nullptr;
-    SearchScratch<T> sc;
-    T* pv = nullptr; long long* pi = nullptr; double* pd = nullptr;   // reduction partials
+    SearchJob<T> xy, yx;                                // x rows searched in y / y rows searched in x
+    T* pv = nullptr; long long* pi = nullptr; double* pd = nullptr;   // reduction partials (per direction: 2 x kRedBlocks)
     T* res_v = nullptr; long long* res_ij = nullptr; double* res_s = nullptr;
+    bool two = true;
 };
 template <typename T>
-static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev, bool need_corr_out) {
-    size_t b = index_bytes<T>(nx, occ) + index_bytes<T>(ny, occ) + scratch_bytes<T>(std::max(nx, ny)) +
+static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
+    size_t b = index_bytes<T>(nx, occ) + index_bytes<T>(ny, occ) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
                align_up((size_t)nx * sizeof(T), 256) + align_up((size_t)ny * sizeof(T), 256) +
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
-               3 * align_up((size_t)kRedBlocks * 8, 256) + 4096;
+               6 * align_up((size_t)kRedBlocks * 8, 256) + 8192;
     if (!on_dev) b += align_up((size_t)nx * 3 * sizeof(T), 256) + align_up((size_t)ny * 3 * sizeof(T), 256);
-    (void)need_corr_out;
     return b;
 }
 template <typename T>
-static int pair_run(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
-                    bool squared, double occ, long long* ext_cxy, long long* ext_cyx, PairState<T>& P, Timer& tm, pcu_hip_stats* st,
-                    bool do_xy, bool do_yx) {
+static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
+                      bool squared, double occ, long long* ext_cxy, long long* ext_cyx, PairState<T>& P, Timer& tm,
+                      pcu_hip_stats* st, bool two_sided) {
+    P.two = two_sided;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
-    if (index_alloc(ar, P.ix, nx, occ) || index_alloc(ar, P.iy, ny, occ)) return -1;
-    if (scratch_alloc(ar, P.sc, std::max(nx, ny))) return -1;
-    if (aalloc(ar, &P.d_xy, (size_t)nx) || aalloc(ar, &P.d_yx, (size_t)ny)) return -1;
-    P.c_xy = ext_cxy; P.c_yx = ext_cyx;
-    if (!P.c_xy && aalloc(ar, &P.c_xy, (size_t)nx)) return -1;
-    if (!P.c_yx && aalloc(ar, &P.c_yx, (size_t)ny)) return -1;
-    if (aalloc(ar, &P.pv, (size_t)kRedBlocks) || aalloc(ar, &P.pi, (size_t)kRedBlocks) || aalloc(ar, &P.pd, (size_t)kRedBlocks)) return -1;
+    GridIndex<T> ix, iy;
+    if (index_alloc(ar, ix, nx, occ) || index_alloc(ar, iy, ny, occ)) return -1;
+    P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
+    P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
+    P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
+    if (scratch_alloc(ar, P.xy.sc, nx) || scratch_alloc(ar, P.yx.sc, ny)) return -1;
+    if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
+    P.xy.out_i = ext_cxy; P.yx.out_i = ext_cyx;
+    if (!P.xy.out_i && aalloc(ar, &P.xy.out_i, (size_t)nx)) return -1;
+    if (!P.yx.out_i && aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
+    if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     if (aalloc(ar, &P.res_v, 4) || aalloc(ar, &P.res_ij, 8) || aalloc(ar, &P.res_s, 4)) return -1;
     tm.mark(0);
-    if (index_build(P.ix, P.dx, occ, s) || index_build(P.iy, P.dy, occ, s)) return -1;
+    if (index_build(ix, P.dx, occ, s) || index_build(iy, P.dy, occ, s)) return -1;
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
-    if (do_xy && knn_device(c, ar, s, P.ix, P.iy, P.dy, occ, 1, squared, P.d_xy, P.c_xy, P.sc, st)) return -1;
-    if (do_yx && knn_device(c, ar, s, P.iy, P.ix, P.dx, occ, 1, squared, P.d_yx, P.c_yx, P.sc, st)) return -1;
+    if (search_enqueue(c, s, P.xy, st)) return -1;
+    if (two_sided && search_enqueue(c, s, P.yx, st)) return -1;
     tm.mark(2);
     return 0;
 }
+// Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
+template <typename T>
+static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
+    int r1 = search_finish(c, ar, s, P.xy, st);
+    if (r1 < 0) return r1;
+    int r2 = P.two ? search_finish(c, ar, s, P.yx, st) : 0;
+    if (r2 < 0) return r2;
+    return (r1 | r2) ? 1 : 0;
+}
 
 template <typename T>
-static int argmax_enqueue(hipStream_t s, const T* d, int n, const long long* corr, PairState<T>& P, int slot) {
+static int argmax_enqueue(hipStream_t s, const SearchJob<T>& j, PairState<T>& P, int slot) {
+    const int n = j.qidx.n;
     const int nb = std::min((n + kBlock - 1) / kBlock, kRedBlocks);
-    hipLaunchKernelGGL(k_argmax_partial<T>, dim3(nb), dim3(kBlock), 0, s, d, n, P.pv, P.pi);
-    hipLaunchKernelGGL(k_argmax_final<T>, dim3(1), dim3(kBlock), 0, s, P.pv, P.pi, nb, corr, P.res_v + slot, P.res_ij + 2 * slot);
+    hipLaunchKernelGGL(k_argmax_partial<T>, dim3(nb), dim3(kBlock), 0, s, j.out_d, n, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks);
+    hipLaunchKernelGGL(k_argmax_final<T>, dim3(1), dim3(kBlock), 0, s, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks, nb, j.out_i,
+                       P.res_v + slot, P.res_ij + 2 * slot);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -386,19 +452,23 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
-    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev, false))) return PCU_HIP_ERR_RUNTIME;
+    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c}; Timer tm{c, s, st};
     int rc = 0;
     do {
         PairState<T> P;
-        if ((rc = pair_run(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, true, two_sided))) break;
-        if ((rc = argmax_enqueue(s, P.d_xy, (int)nx, P.c_xy, P, 0))) break;
-        if (two_sided && (rc = argmax_enqueue(s, P.d_yx, (int)ny, P.c_yx, P, 1))) break;
-        tm.mark(3);
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided))) break;
         T hv[2]; long long hij[4];
-        HIP_TRY(hipMemcpyAsync(hv, P.res_v, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(hij, P.res_ij, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
+            if (two_sided && (rc = argmax_enqueue(s, P.yx, P, 1))) break;
+            tm.mark(3);
+            HIP_TRY(hipMemcpyAsync(hv, P.res_v, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(hij, P.res_ij, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
+            else HIP_TRY(hipStreamSynchronize(s));
+        }
+        if (rc) break;
         const int nres = two_sided ? 2 : 1;
         for (int r = 0; r < nres; ++r) { out_d[r] = hv[r]; out_i[r] = hij[2 * r]; out_j[r] = hij[2 * r + 1]; }
         if (st) { st->n_queries = two_sided ? nx + ny : nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
@@ -425,30 +495,35 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
-    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev, true))) return PCU_HIP_ERR_RUNTIME;
+    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c}; Timer tm{c, s, st};
     int rc = 0;
     do {
         PairState<T> P;
         long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
         long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
-        if ((rc = pair_run(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, true))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true))) break;
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
         const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);
-        hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.dx, P.dy, P.c_xy, P.d_xy, (int)nx, pc, p_norm, P.pd);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nbx, P.res_s + 0);
-        hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nby), dim3(kBlock), 0, s, P.dy, P.dx, P.c_yx, P.d_yx, (int)ny, pc, p_norm, P.pd);
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nby, P.res_s + 1);
-        HIP_TRY(hipGetLastError());
-        tm.mark(3);
         double hs[2];
-        HIP_TRY(hipMemcpyAsync(hs, P.res_s, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (!on_dev) {
-            if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.c_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
-            if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.c_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.dx, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, pc, p_norm, P.pd);
+            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nbx, P.res_s + 0);
+            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nby), dim3(kBlock), 0, s, P.dy, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, pc, p_norm, P.pd + kRedBlocks);
+            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd + kRedBlocks, nby, P.res_s + 1);
+            HIP_TRY(hipGetLastError());
+            tm.mark(3);
+            HIP_TRY(hipMemcpyAsync(hs, P.res_s, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st); if (rc <= 0) break; rc = 0; }
+            else HIP_TRY(hipStreamSynchronize(s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        if (rc) break;
+        if (!on_dev) {
+            if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.xy.out_i, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+            if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.yx.out_i, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         out_mean2[0] = hs[0] / (double)nx;
         out_mean2[1] = hs[1] / (double)ny;
         if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }

@@ -49,7 +49,6 @@ struct GridParams {
     T slack[3];               // conservative slack on cell-face positions (certification, see search.h)
     int G[3];                 // cells per axis
     int ncells;               // G[0]*G[1]*G[2]
-    typename EncT<T>::type emin[3], emax[3];   // atomic bbox accumulators (encoded)
 };
 
 // Cell coordinate of value v along one axis. Separate subtract and multiply (the TU is built with

@@ -25,6 +25,7 @@
 // (see tie_order.h).
 #pragma once
 #include "pcu_types.h"
+#include "grid.h"
 
 namespace pcu {
 
@@ -196,6 +197,98 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     }
     wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
     wave_append(certified && tie, qpos, a.ties, a.n_ties);
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Wave-cooperative search: ONE WAVE per query, for the few queries the lane-per-query pass could not finish
+// (escalation to a wider radius R, or re-resolution of a possible tie). The (2R+1)^2 rows of the query's cell
+// box are dealt to the 64 lanes (lane <- row); each lane keeps the K best of its rows in registers under the
+// total order (d2, dataset row); the K global best are then extracted by K rounds of a wave-wide
+// lexicographic arg-min (DPP/shuffle butterflies), which also exposes genuine ties (equal d2 at consecutive
+// ranks up to the (k+1)-th). Work items come from a device-side list + count, so the launch needs no host
+// round trip: the grid is fixed and waves stride over the list.
+template <typename T>
+__device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d < d2 || (d == d2 && id < id2); }
+
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * kBlock) >> 6;
+    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    const GridParams<T>& g = *a.gp;
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int R = a.R, kreq = a.kreq;
+    for (int w = wave; w < nq; w += nwaves) {
+        const int qpos = a.qlist ? a.qlist[w] : w;
+        const Pt4<T> q = a.qsorted[qpos];
+        const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
+        const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
+        const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+        const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
+        const int y0 = max(ccy - R, 0), y1 = min(ccy + R, Gy - 1);
+        const int z0 = max(ccz - R, 0), z1 = min(ccz + R, Gz - 1);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+
+        T bd[K]; int bi[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
+        for (int r = lane; r < nrows; r += 64) {
+            const int cz = z0 + r / ny, cy = y0 + r % ny;
+            const int row = (cz * Gy + cy) * Gx;
+            const unsigned s = a.cell_start[row + x0], e = a.cell_start[row + x1 + 1];
+            for (unsigned p = s; p < e; ++p) {
+                const Pt4<T> c = a.ref[p];
+                const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                const int id = (int)c.idx;
+                if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
+#pragma unroll
+                    for (int i = K - 1; i > 0; --i) {
+                        const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
+                        const bool gi = lex_less(d, id, bd[i], bi[i]);
+                        bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+                        bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                    }
+                    if (K == 1 || lex_less(d, id, bd[0], bi[0])) { bd[0] = d; bi[0] = id; }
+                }
+            }
+        }
+        // K rounds: global lexicographic minimum of the lanes' heads; the owner pops.
+        T my_d = Limits<T>::max_v; int my_i = 0x7fffffff;    // lane j keeps rank j
+        T prev_d = (T)-1; T kth = Limits<T>::max_v; bool tie = false;
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            T md = bd[0]; int mi = bi[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const T od = __shfl_xor(md, o, 64); const int oi = __shfl_xor(mi, o, 64);
+                if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
+            }
+            if (bi[0] == mi && bd[0] == md && mi != 0x7fffffff) {          // owner (dataset rows are unique)
+#pragma unroll
+                for (int i = 0; i < K - 1; ++i) { bd[i] = bd[i + 1]; bi[i] = bi[i + 1]; }
+                bd[K - 1] = Limits<T>::max_v; bi[K - 1] = 0x7fffffff;
+            }
+            if (lane == j) { my_d = md; my_i = mi; }
+            if (j <= kreq && mi != 0x7fffffff && md == prev_d) tie = true;
+            if (j == kreq - 1) kth = md;
+            prev_d = md;
+        }
+        const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+        const bool certified = kth < lb;
+        if (certified) {
+            if (lane < kreq) {
+                const size_t o = (size_t)q.idx * (size_t)kreq + lane;
+                const bool found = my_i != 0x7fffffff;
+                a.out_i[o] = found ? (long long)my_i : -1ll;
+                a.out_d[o] = found ? (a.squared ? my_d : sqrt(my_d)) : (T)-1;
+            }
+            if (tie && lane == 0) a.ties[atomicAdd(a.n_ties, 1)] = qpos;
+        } else if (lane == 0) {
+            a.unresolved[atomicAdd(a.n_unresolved, 1)] = qpos;
+        }
+    }
 }
 
 }  // namespace pcu

@@ -99,14 +99,29 @@ def _assert_knn(pcu, d, c, d0, c0):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
-    """Disjoint / offset clouds force radius escalation and the coarse-grid fallback."""
+    """Offset clouds, isolated clusters and anisotropic data: radius escalation and the coarse-grid fallback."""
     q = cloud(5, 20000, dtype, scale=0.3, offset=2.0)
     r = cloud(6, 30000, dtype)
     for k in (1, 4):
         d, c = pcu.k_nearest_neighbors(q, r, k)
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
         _assert_knn(pcu, d, c, d0, c0)
-    assert pcu.last_stats()["n_escalated"] > 0
+    # two far-apart dataset clusters, queries everywhere in between: most queries need a wider radius,
+    # the ones in the middle need the coarse grids
+    r = np.concatenate([cloud(7, 20000, dtype, scale=0.1), cloud(8, 20000, dtype, scale=0.1, offset=0.9)])
+    q = cloud(9, 30000, dtype)
+    for k in (1, 3):
+        d, c = pcu.k_nearest_neighbors(q, r, k)
+        st = pcu.last_stats()
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+        _assert_knn(pcu, d, c, d0, c0)
+        assert st["n_escalated"] > 1000 and st["n_grid_builds"] > 2, st
+    h = pcu.hausdorff_distance(q, r, return_index=True)
+    h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
+    assert h[0] == h0[0]
+    ch = pcu.chamfer_distance(q, r)
+    ch0 = oracle.chamfer_distance(q, r, kind=oracle_kind)
+    assert abs(float(ch) - float(ch0)) <= 1e-4 * float(ch0)
     # anisotropic + clustered
     rng = np.random.default_rng(9)
     r = (rng.standard_normal((40000, 3)) * np.array([1.0, 0.05, 0.3])).astype(dtype)
