@@ -15,9 +15,9 @@ Inputs may be numpy arrays (host; copied to the GPU for the call, results return
 exactly as the reference returns them) or, as an extension, CUDA/HIP ``torch`` tensors (device-resident: nothing
 crosses PCIe, array results are returned as ``torch`` tensors on the same device).
 
-``max_points_per_leaf`` and ``num_threads`` are kd-tree / OpenMP knobs of the reference; they are accepted for
-signature compatibility and do not influence results (the reference's results do not depend on them either,
-except for the order of exact distance ties, which follows ``max_points_per_leaf``'s tree).
+``num_threads`` is an OpenMP knob of the reference: accepted, ignored. ``max_points_per_leaf`` is the reference's
+kd-tree leaf size: it cannot change distances, but the order of *exactly tied* neighbours in the reference is the
+order its kd-tree traversal meets them, so it is forwarded and that order is reproduced on the GPU.
 """
 import ctypes
 
@@ -138,7 +138,7 @@ def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False
         dataset_points : m by 3 array of representing a set of m points (each row is a point of dimension 3).
         k : the number of nearest neighbors to query per point.
         squared_distances : If set to True, then return squared L2 distances. Default is False.
-        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        max_points_per_leaf : leaf size of the reference's kd-tree. Does not change distances; it only fixes the order of exactly tied neighbours, which is reproduced.
         num_threads : OpenMP knob of the reference; accepted and ignored.
 
     Returns:
@@ -157,7 +157,7 @@ def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False
     st = Stats()
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
     with _lib.lock():
-        rc = getattr(_lib.lib(), "pcu_hip_knn_" + d.suffix)(d.ctx, d.pa, n, d.pb, m, k, _Dev.ptr(dists), _Dev.ptr(corrs),
+        rc = getattr(_lib.lib(), "pcu_hip_knn_" + d.suffix)(d.ctx, d.pa, n, d.pb, m, k, int(max_points_per_leaf), _Dev.ptr(dists), _Dev.ptr(corrs),
                                                            flags, d.stream, ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
@@ -181,7 +181,7 @@ def one_sided_hausdorff_distance(source, target, return_index=True, squared_dist
         target : m by 3 array of representing a set of m points (each row is a point of dimension 3)
         return_index : Optionally return the index pair `(i, j)` into source and target such that `source[i, :]` and `target[j, :]` are the two points with maximum shortest distance.
         squared_distances : If set to True, then return squared L2 distances.
-        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        max_points_per_leaf : leaf size of the reference's kd-tree. Does not change distances; it only fixes the order of exactly tied neighbours, which is reproduced.
 
     Returns:
         d : The largest shortest distance, `d` between each point in `source` and the points in `target`.
@@ -197,7 +197,8 @@ def one_sided_hausdorff_distance(source, target, return_index=True, squared_dist
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
     with _lib.lock():
         rc = getattr(_lib.lib(), "pcu_hip_one_sided_hausdorff_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream, ctypes.addressof(st))
+            d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
+            ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
     if return_index:
@@ -214,7 +215,7 @@ def hausdorff_distance(x, y, return_index=False, squared_distances=False, max_po
         y : m by 3 array of representing a set of m points (each row is a point of dimension 3)
         return_index : Optionally return the index pair `(i, j)` into x and y such that `x[i, :]` and `y[j, :]` are the two points with maximum shortest distance.
         squared_distances : If set to True, then return squared L2 distances. Default is False.
-        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        max_points_per_leaf : leaf size of the reference's kd-tree. Does not change distances; it only fixes the order of exactly tied neighbours, which is reproduced.
 
     Returns:
         The largest shortest distance, `d` between each point in `source` and the points in `target`.
@@ -230,7 +231,8 @@ def hausdorff_distance(x, y, return_index=False, squared_distances=False, max_po
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
     with _lib.lock():   # one call: both clouds are indexed once and searched in both directions
         rc = getattr(_lib.lib(), "pcu_hip_hausdorff_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream, ctypes.addressof(st))
+            d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
+            ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
     # point_cloud_utils/__init__.py:69-81, on Python floats exactly as there
@@ -255,7 +257,7 @@ def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10)
                     corrs_x_to_y[i] stores the index into y of the closest point to x[i]
                     (i.e. y[corrs_x_to_y[i]] is the nearest neighbor to x[i] in y).
                     corrs_y_to_x is similar to corrs_x_to_y but with x and y reversed.
-        max_points_per_leaf : kd-tree knob of the reference; accepted and ignored.
+        max_points_per_leaf : leaf size of the reference's kd-tree. Does not change distances; it only fixes the order of exactly tied neighbours, which is reproduced.
         p_norm : Which norm to use. p_norm can be any real number, inf (for the max norm) -inf (for the min norm),
                 0 (for sum(x != 0))
     Returns:
@@ -271,7 +273,7 @@ def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10)
     st = Stats()
     with _lib.lock():
         rc = getattr(_lib.lib(), "pcu_hip_chamfer_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, float(p_norm), means.ctypes.data, _Dev.ptr(cxy), _Dev.ptr(cyx),
+            d.ctx, d.pa, n, d.pb, m, float(p_norm), int(max_points_per_leaf), means.ctypes.data, _Dev.ptr(cxy), _Dev.ptr(cyx),
             d.flags, d.stream, ctypes.addressof(st))
     _lib.check(rc)
     _record(st)

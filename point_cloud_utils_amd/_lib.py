@@ -71,10 +71,12 @@ def lib():
         L.pcu_hip_ctx_set_cell_occupancy.argtypes = [ctypes.c_void_p, ctypes.c_double]
         vp, i64, ci, u = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint
         for suf in ("f32", "f64"):
-            getattr(L, "pcu_hip_knn_" + suf).argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, u, vp, vp]
-            getattr(L, "pcu_hip_one_sided_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, u, vp, vp]
-            getattr(L, "pcu_hip_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, u, vp, vp]
-            getattr(L, "pcu_hip_chamfer_" + suf).argtypes = [vp, vp, i64, vp, i64, ctypes.c_double, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_knn_" + suf).argtypes = [vp, vp, i64, vp, i64, ci, ci, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_one_sided_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_hausdorff_" + suf).argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_chamfer_" + suf).argtypes = [vp, vp, i64, vp, i64, ctypes.c_double, ci, vp, vp, vp, u, vp, vp]
+        for suf in ("f32", "f64"):
+            getattr(L, "pcu_hip_debug_kd_tree_" + suf).argtypes = [vp, vp, i64, ci, vp, vp]
         _lib = L
     return _lib
 

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "grid.h"
 #include "reduce.h"
 #include "search.h"
+#include "kd_order.h"
 
 using namespace pcu;
 
@@ -202,6 +204,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     const T* d_ref_pts = nullptr;
     double occ = 1.5;
     int k = 1; bool squared = false;
+    int leaf_max = 10; bool tie_order = true;   // reference's max_points_per_leaf: defines the order of exact ties
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
 };
@@ -243,6 +246,81 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
     return 0;
 }
 
+// Exact ties: rebuild nanoflann's kd-tree on the GPU and re-run the tied queries through nanoflann's own
+// traversal (kd_order.h). Only called when the grid search reported genuine ties.
+template <typename T>
+static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
+                           KdBuild<T>& b, int** err_out, int* levels_out) {
+    const size_t max_nodes = 2 * (size_t)M + 2, max_level = (size_t)M + 2, max_items = (size_t)M / kKdChunk + max_level + 2;
+    int* counters = nullptr;
+    if (aalloc(ar, &b.E, (size_t)M) || aalloc(ar, &b.nodes, max_nodes) || aalloc(ar, &counters, 16)) return -1;
+    if (aalloc(ar, &b.level_nodes, max_level) || aalloc(ar, &b.next_nodes, max_level)) return -1;
+    if (aalloc(ar, &b.item_node, max_items) || aalloc(ar, &b.item_chunk, max_items)) return -1;
+    if (aalloc(ar, &b.chunk_bl, max_items) || aalloc(ar, &b.chunk_br, max_items)) return -1;
+    if (aalloc(ar, &b.BLpos, (size_t)M) || aalloc(ar, &b.BRpos, (size_t)M)) return -1;
+    b.n_nodes = counters; b.n_next = counters + 1; b.n_items = counters + 2;
+    *err_out = counters + 3;
+    b.leaf_max = leaf_max;
+    HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
+    hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
+    hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
+    int n_level = 1, level_count = 0;
+    const bool dbg = getenv("PCU_HIP_DEBUG_KD") != nullptr;
+    for (int level = 0; n_level > 0; ++level) {
+        if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
+        const int items_ub = M / kKdChunk + n_level + 1;
+        const int nlb = (n_level + kBlock - 1) / kBlock;
+#define KD_STEP(name, ...) do { __VA_ARGS__; if (dbg) { hipError_t e_ = hipStreamSynchronize(s); fprintf(stderr, "[kd] level %d n=%d %s -> %s\n", level, n_level, name, hipGetErrorString(e_)); } } while (0)
+        KD_STEP("plan", hipLaunchKernelGGL(k_kd_plan<T>, dim3(1), dim3(kBlock), 0, s, b, n_level));
+        KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
+        KD_STEP("choose", hipLaunchKernelGGL(k_kd_choose<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level));
+        KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
+        for (int ph = 0; ph < 2; ++ph) {
+            KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+            KD_STEP("chunk_scan", hipLaunchKernelGGL(k_kd_chunk_scan<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level, ph));
+            KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+            KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+        }
+        KD_STEP("split", hipLaunchKernelGGL(k_kd_split<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level));
+#undef KD_STEP
+        HIP_TRY(hipGetLastError());
+        int n_next = 0;
+        HIP_TRY(hipMemcpyAsync(&n_next, b.n_next, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::swap(b.level_nodes, b.next_nodes);
+        n_level = n_next;
+        level_count = level + 1;
+    }
+    (void)c;
+    *levels_out = level_count;
+    return 0;
+}
+
+template <typename T>
+static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, int n_tt, pcu_hip_stats* st) {
+    KdBuild<T> b; int* err = nullptr; int levels = 0;
+    hipEvent_t e0 = c->ev[4], e1 = c->ev[5];
+    if (st) (void)hipEventRecord(e0, s);
+    if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels)) return -1;
+    KdSearchArgs<T> a;
+    a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
+    a.k = j.k; a.squared = j.squared ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
+    if (aalloc(ar, &a.scratch_d, (size_t)n_tt * j.k) || aalloc(ar, &a.scratch_i, (size_t)n_tt * j.k)) return -1;
+    KdFrame<T>* frames = nullptr;
+    a.stack_cap = levels + 2;
+    if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
+    a.stack = frames;
+    hipLaunchKernelGGL(k_kd_search<T>, dim3((n_tt + 63) / 64), dim3(64), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    if (st) (void)hipEventRecord(e1, s);
+    int herr = 0;
+    HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
+    if (st) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
+    return 0;
+}
+
 // After a stream sync: read the counters; finish whatever is still unresolved with coarser dataset grids
 // (host-driven, one sync per pass; only far-away / isolated queries ever get here).
 // Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, <0 on error.
@@ -253,7 +331,11 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     HIP_TRY(hipStreamSynchronize(s));
     if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
     int n_left = hc[C_U3];
-    if (n_left == 0) { if (st) st->n_tie_true += hc[C_TT]; return 0; }
+    if (n_left == 0) {
+        if (st) st->n_tie_true += hc[C_TT];
+        if (hc[C_TT] > 0 && j.tie_order) { if (tie_order_resolve(c, ar, s, j, hc[C_TT], st)) return -1; return 1; }
+        return 0;
+    }
     const int KL = std::max(2, pow2_at_least(j.k + 1));
     int* cur = j.sc.u3; int* nxt = j.sc.u1;
     double occ = j.occ;
@@ -291,6 +373,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     int tt = 0;
     HIP_TRY(hipMemcpy(&tt, j.sc.counters + C_TT, sizeof(int), hipMemcpyDeviceToHost));
     if (st) st->n_tie_true += tt;
+    if (tt > 0 && j.tie_order && tie_order_resolve(c, ar, s, j, tt, st)) return -1;
     return 1;
 }
 
@@ -324,7 +407,7 @@ static int stage_in(Arena& ar, const T* p, int64_t n, bool on_dev, hipStream_t s
 
 // ------------------------------------------------------------------------------------------------ knn
 template <typename T>
-static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k,
+static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
                     T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (k <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid value for k (%d) must be greater than 0.", k);
@@ -353,6 +436,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = index_alloc(ar, job.qidx, nq, occ_q))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq))) break;
         job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared; job.out_d = dd; job.out_i = di;
+        job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
         if ((rc = index_build(job.ridx, dr, occ, s))) break;
         if ((rc = index_build(job.qidx, dq, occ_q, s))) break;
@@ -397,8 +481,9 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
 template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
                       bool squared, double occ, long long* ext_cxy, long long* ext_cyx, PairState<T>& P, Timer& tm,
-                      pcu_hip_stats* st, bool two_sided) {
+                      pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order) {
     P.two = two_sided;
+    P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = P.yx.tie_order = tie_order;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
@@ -444,7 +529,7 @@ static int argmax_enqueue(hipStream_t s, const SearchJob<T>& j, PairState<T>& P,
 }
 
 template <typename T>
-static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided,
+static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided, int max_leaf,
                           T* out_d, int64_t* out_i, int64_t* out_j, unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "source", "targets")) return PCU_HIP_ERR_INVALID;
@@ -457,7 +542,7 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     int rc = 0;
     do {
         PairState<T> P;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided, max_leaf, !(flags & PCU_HIP_NO_TIE_ORDER)))) break;
         T hv[2]; long long hij[4];
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
@@ -486,7 +571,7 @@ static int pcode_of(double p) {
 }
 
 template <typename T>
-static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, double* out_mean2,
+static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf, double* out_mean2,
                         int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
@@ -502,7 +587,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         PairState<T> P;
         long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
         long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, max_leaf, !(flags & PCU_HIP_NO_TIE_ORDER)))) break;
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
         const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);
@@ -527,6 +612,34 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         out_mean2[0] = hs[0] / (double)nx;
         out_mean2[1] = hs[1] / (double)ny;
         if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+
+// Diagnostic hook for tests: builds the nanoflann-faithful kd-tree of `pts` on the GPU and returns its
+// permutation (vAcc) and node count, so the tree itself can be compared with the oracle's.
+template <typename T>
+static int debug_kd(pcu_hip_ctx* c, const T* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) {
+    if (!c || n <= 0) return fail(PCU_HIP_ERR_INVALID, "bad arguments");
+    hipStream_t s = c->own_stream;
+    if (ctx_begin(c, index_bytes<T>(n, 2.0) + (size_t)n * 3 * sizeof(T) + 8192)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T* dp;
+        if ((rc = stage_in(ar, pts, n, false, s, &dp))) break;
+        GridIndex<T> gi;
+        if ((rc = index_alloc(ar, gi, n, 2.0))) break;
+        if ((rc = index_build(gi, dp, 2.0, s))) break;
+        KdBuild<T> b; int* err = nullptr; int levels = 0;
+        if ((rc = kd_build_device(c, ar, s, dp, (int)n, gi.gp, leaf_max > 0 ? leaf_max : 10, b, &err, &levels))) break;
+        std::vector<Pt4<T>> h((size_t)n);
+        int nn = 0;
+        HIP_TRY(hipMemcpy(h.data(), b.E, (size_t)n * sizeof(Pt4<T>), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&nn, b.n_nodes, sizeof(int), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) out_vacc[i] = (int64_t)h[(size_t)i].idx;
+        *out_nnodes = nn;
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -574,23 +687,26 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
 int pcu_hip_ctx_set_cell_occupancy(pcu_hip_ctx* c, double ppc) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->occupancy = ppc; return 0; }
 int64_t pcu_hip_ctx_workspace_bytes(pcu_hip_ctx* c) { return c ? (int64_t)c->arena_cap : 0; }
 
-int pcu_hip_knn_f32(pcu_hip_ctx* c, const float* q, int64_t nq, const float* r, int64_t nr, int k, float* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<float>(c, q, nq, r, nr, k, od, oi, flags, stream, st); }
-int pcu_hip_knn_f64(pcu_hip_ctx* c, const double* q, int64_t nq, const double* r, int64_t nr, int k, double* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<double>(c, q, nq, r, nr, k, od, oi, flags, stream, st); }
+int pcu_hip_knn_f32(pcu_hip_ctx* c, const float* q, int64_t nq, const float* r, int64_t nr, int k, int max_leaf, float* od, int64_t* oi,
+                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<float>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
+int pcu_hip_knn_f64(pcu_hip_ctx* c, const double* q, int64_t nq, const double* r, int64_t nr, int k, int max_leaf, double* od, int64_t* oi,
+                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<double>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
 
-int pcu_hip_one_sided_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, float* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, false, od, oi, oj, flags, stream, st); }
-int pcu_hip_one_sided_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, double* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, false, od, oi, oj, flags, stream, st); }
-int pcu_hip_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, float* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, true, od, oi, oj, flags, stream, st); }
-int pcu_hip_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, double* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, true, od, oi, oj, flags, stream, st); }
+int pcu_hip_one_sided_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+int pcu_hip_one_sided_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+int pcu_hip_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
+                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
+int pcu_hip_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
+                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
 
-int pcu_hip_chamfer_f32(pcu_hip_ctx* c, const float* x, int64_t nx, const float* y, int64_t ny, double p, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<float>(c, x, nx, y, ny, p, om, cxy, cyx, flags, stream, st); }
-int pcu_hip_chamfer_f64(pcu_hip_ctx* c, const double* x, int64_t nx, const double* y, int64_t ny, double p, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<double>(c, x, nx, y, ny, p, om, cxy, cyx, flags, stream, st); }
+int pcu_hip_chamfer_f32(pcu_hip_ctx* c, const float* x, int64_t nx, const float* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
+                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<float>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+int pcu_hip_chamfer_f64(pcu_hip_ctx* c, const double* x, int64_t nx, const double* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
+                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<double>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+
+int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
+int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
 
 }  // extern "C"

@@ -43,23 +43,40 @@ def cloud(seed, n, dtype, scale=1.0, offset=0.0):
 
 
 def read_ply_vertices(path):
-    """Minimal binary-little-endian PLY vertex reader (x,y,z float/double first in the vertex element)."""
+    """Minimal binary-little-endian PLY reader returning the (n,3) x,y,z of the `vertex` element. Elements may
+    come in any order (data/bunny_duplicates.ply stores faces first); list properties are walked to skip them."""
+    import struct
+    m = {"char": "b", "uchar": "B", "short": "h", "ushort": "H", "int": "i", "uint": "I", "float": "f", "double": "d",
+         "int8": "b", "uint8": "B", "int16": "h", "uint16": "H", "int32": "i", "uint32": "I", "float32": "f", "float64": "d"}
     with open(path, "rb") as f:
         assert f.readline().strip() == b"ply"
-        fmt = None; n = 0; props = []; in_vertex = False
+        fmt = None; elements = []
         while True:
             line = f.readline().strip()
             if line == b"end_header":
                 break
             tok = line.split()
             if tok[0] == b"format": fmt = tok[1]
-            elif tok[0] == b"element":
-                in_vertex = tok[1] == b"vertex"
-                if in_vertex: n = int(tok[2])
-            elif tok[0] == b"property" and in_vertex:
-                props.append((tok[2].decode(), tok[1].decode()))
+            elif tok[0] == b"element": elements.append([tok[1].decode(), int(tok[2]), []])
+            elif tok[0] == b"property":
+                if tok[1] == b"list": elements[-1][2].append(("list", tok[2].decode(), tok[3].decode(), tok[4].decode()))
+                else: elements[-1][2].append((tok[2].decode(), tok[1].decode()))
         assert fmt == b"binary_little_endian"
-        m = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8", "uchar": "u1", "int": "<i4", "uint": "<u4"}
-        dt = np.dtype([(nm, m[t]) for nm, t in props])
-        v = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
-    return np.stack([v["x"], v["y"], v["z"]], axis=-1)
+        for name, count, props in elements:
+            has_list = any(p[0] == "list" for p in props)
+            if name == "vertex":
+                assert not has_list
+                dt = np.dtype([(nm, "<" + m[t]) for nm, t in props])
+                v = np.frombuffer(f.read(count * dt.itemsize), dtype=dt, count=count)
+                return np.stack([v["x"], v["y"], v["z"]], axis=-1)
+            if not has_list:
+                f.seek(count * sum(struct.calcsize(m[t]) for _, t in props), 1)
+            else:
+                for _ in range(count):
+                    for p in props:
+                        if p[0] == "list":
+                            (c,) = struct.unpack("<" + m[p[1]], f.read(struct.calcsize(m[p[1]])))
+                            f.seek(c * struct.calcsize(m[p[2]]), 1)
+                        else:
+                            f.seek(struct.calcsize(m[p[1]]), 1)
+    raise ValueError("no vertex element")

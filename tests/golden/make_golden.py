@@ -49,6 +49,12 @@ def main():
     dup = read_ply_vertices(os.path.join(REF_DATA, "bunny_duplicates.ply"))
     add("bunny_vs_dup_f32", bunny.astype(np.float32)[::3], dup.astype(np.float32), 2)
     add("dup_self_f64", dup.astype(np.float64)[::2], dup.astype(np.float64), 3)
+    # extreme dynamic range: exponents spread over the whole fp32 range -> kd-tree hundreds of levels deep,
+    # d2 overflowing to +inf for most pairs
+    bits = rng.integers(0, 2**32, (3000, 3), dtype=np.uint64).astype(np.uint32)
+    ext = bits.view(np.float32).copy(); ext[~np.isfinite(ext)] = 1.0
+    add("extreme_range_k2_f32", ext[::3], ext, 2)
+    add("extreme_range_small_k3_f32", (ext * np.float32(1e-20))[::5], ext * np.float32(1e-20), 3)
 
     for name, c in cases.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)

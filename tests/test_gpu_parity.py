@@ -39,21 +39,7 @@ def test_golden_knn(pcu, path):
     d0, c0 = _squeeze(g["d"], g["c"], k, g["q"].shape[0])
     assert d.shape == d0.shape and c.shape == c0.shape and c.dtype == np.int64 and d.dtype == g["q"].dtype
     assert np.array_equal(d.view(np.uint8), d0.view(np.uint8)), "distances differ"
-    if any(t in os.path.basename(path) for t in TIE_CASES):
-        # distances are unique; indices may differ only where the reference's kd-tree traversal orders exact ties
-        same = c == c0
-        if not same.all():
-            bad = ~same
-            q, r = g["q"], g["r"]
-            # every differing index must still be a correct neighbour at that distance
-            qq = np.repeat(np.arange(q.shape[0]), k).reshape(c0.shape)[bad] if c0.ndim > 1 else np.nonzero(bad)[0]
-            diff = q[qq] - r[c[bad]]
-            d2 = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
-            dd = d if bool(g["squared"]) else d * d
-            assert np.allclose(d2, dd[bad], rtol=1e-5)
-        pytest.xfail("kd-tree tie order not reproduced yet") if not same.all() else None
-    else:
-        assert np.array_equal(c, c0), "indices differ"
+    assert np.array_equal(c, c0), f"indices differ {pcu.last_stats()}"     # incl. exact ties: kd-tree traversal order
 
 
 def test_golden_metrics(pcu):
@@ -83,18 +69,14 @@ def test_seeded_vs_oracle(pcu, oracle_kind, dtype, n, m, k):
     st = pcu.last_stats()
     d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
     assert np.array_equal(d, d0), f"distances differ {st}"
-    if st["n_tie_true"] == 0:
-        assert np.array_equal(c, c0), f"indices differ {st}"
-    else:
-        assert (c != c0).any(axis=-1).sum() <= st["n_tie_true"]
+    assert np.array_equal(c, c0), f"indices differ {st}"
 
 
 def _assert_knn(pcu, d, c, d0, c0):
-    """distances bit-equal; indices equal except (until the kd-order resolver lands) rows with a genuine tie."""
+    """distances and indices bit-equal (exact ties included)."""
     st = pcu.last_stats()
     assert np.array_equal(d, d0), f"distances differ {st}"
-    nbad = int((c != c0).reshape(c.shape[0], -1).any(axis=-1).sum())
-    assert nbad <= st["n_tie_true"], f"{nbad} rows differ, {st}"
+    assert np.array_equal(c, c0), f"indices differ {st}"
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -239,3 +221,34 @@ def test_torch_device_resident(pcu, oracle_kind):
     ch, cxy, cyx = pcu.chamfer_distance(tq, tr, return_index=True)
     ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=oracle_kind)
     assert np.array_equal(cxy.cpu().numpy(), cxy0) and abs(float(ch) - float(ch0)) < 1e-4 * float(ch0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("leaf", [10, 1, 33])
+def test_gpu_kd_tree_is_nanoflanns_tree(pcu, dtype, leaf):
+    """The tie-order resolver's GPU-built kd-tree must be nanoflann's tree: same permutation vAcc, same node count
+    (compared with the restatement, which is itself pinned bit-exactly to the reference's nanoflann)."""
+    import ctypes
+    from point_cloud_utils_amd import _lib
+    rng = np.random.default_rng(3)
+    base = rng.random((6000, 3)).astype(dtype)
+    clouds = {
+        "uniform": rng.random((20000, 3)).astype(dtype),
+        "duplicates": np.concatenate([base, base, base[:1000]]),
+        "lattice": np.stack(np.meshgrid(*[np.arange(17)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(dtype),
+        "planar": (rng.random((9000, 3)) * np.array([1, 1, 0])).astype(dtype),
+        "line_dups": np.repeat(rng.random((300, 3)).astype(dtype), 20, axis=0),
+        "tiny": rng.random((7, 3)).astype(dtype),
+        "all_same": np.ones((500, 3), dtype=dtype),
+    }
+    suf = "f32" if dtype == np.float32 else "f64"
+    for name, pts in clouds.items():
+        pts = np.ascontiguousarray(pts)
+        vacc0, ni, nf, nlr = oracle.tree_dump(pts, leaf)
+        vacc = np.empty(pts.shape[0], np.int64)
+        nn = ctypes.c_int64(0)
+        rc = getattr(_lib.lib(), "pcu_hip_debug_kd_tree_" + suf)(_lib.ctx(), pts.ctypes.data, pts.shape[0], leaf,
+                                                               vacc.ctypes.data, ctypes.addressof(nn))
+        assert rc == 0, _lib.last_error()
+        assert nn.value == ni.shape[0], (name, nn.value, ni.shape[0])
+        assert np.array_equal(vacc, vacc0), name
