@@ -190,11 +190,12 @@ struct SearchScratch {
 template <typename T>
 static size_t scratch_bytes(int64_t nq) { return 5 * align_up((size_t)nq * 4, 256) + 256; }
 template <typename T>
-static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq) {
+static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq, int* counters_ext = nullptr) {
     sc.nq = (int)nq;
     if (aalloc(a, &sc.u1, (size_t)nq) || aalloc(a, &sc.u2, (size_t)nq) || aalloc(a, &sc.u3, (size_t)nq)) return -1;
     if (aalloc(a, &sc.t1, (size_t)nq) || aalloc(a, &sc.tt, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.counters, C_N)) return -1;
+    sc.counters = counters_ext;
+    if (!sc.counters && aalloc(a, &sc.counters, C_N)) return -1;
     return 0;
 }
 
@@ -321,14 +322,13 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     return 0;
 }
 
-// After a stream sync: read the counters; finish whatever is still unresolved with coarser dataset grids
+// After the call's single read-back + stream sync: look at the counters; finish whatever is still unresolved with coarser dataset grids
 // (host-driven, one sync per pass; only far-away / isolated queries ever get here).
 // Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, <0 on error.
 template <typename T>
-static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st) {
-    int hc[C_N];
-    HIP_TRY(hipMemcpyAsync(hc, j.sc.counters, sizeof hc, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc) {
+    // hc: host copy of j.sc.counters, read back by the caller together with the call's scalar results
+    // (one D2H copy + one stream sync for the whole call in the common case)
     if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
     int n_left = hc[C_U3];
     if (n_left == 0) {
@@ -376,6 +376,17 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     if (tt > 0 && j.tie_order && tie_order_resolve(c, ar, s, j, tt, st)) return -1;
     return 1;
 }
+
+// One 256-byte device block per call holds everything the host must read back: both directions' counters and
+// the scalar results. It is copied to pinned host memory with a single hipMemcpyAsync.
+struct ResultBlock {
+    int counters[2][C_N];        //   0..63   bytes
+    double sums[2];              //  64..79
+    double vals[2];              //  80..95   (T-typed values stored in the first sizeof(T) bytes of each slot pair)
+    long long ij[4];             //  96..127
+    int pad[32];
+};
+static_assert(sizeof(ResultBlock) == 256, "ResultBlock layout");
 
 // ------------------------------------------------------------------------------------------------ validation
 static int validate_sizes(int64_t nq, int64_t nr, const char* qname, const char* rname) {
@@ -434,7 +445,9 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         SearchJob<T> job;
         if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
         if ((rc = index_alloc(ar, job.qidx, nq, occ_q))) break;
-        if ((rc = scratch_alloc(ar, job.sc, nq))) break;
+        ResultBlock* rb = nullptr;
+        if ((rc = aalloc(ar, &rb, 1))) break;
+        if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
         job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared; job.out_d = dd; job.out_i = di;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
@@ -443,7 +456,9 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st))) break;
-        if ((rc = search_finish(c, ar, s, job, st)) < 0) break;
+        HIP_TRY(hipMemcpyAsync(c->h_pinned, rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
         rc = 0;
         tm.mark(2);
         if (!on_dev) {
@@ -467,6 +482,7 @@ struct PairState {
     SearchJob<T> xy, yx;                                // x rows searched in y / y rows searched in x
     T* pv = nullptr; long long* pi = nullptr; double* pd = nullptr;   // reduction partials (per direction: 2 x kRedBlocks)
     T* res_v = nullptr; long long* res_ij = nullptr; double* res_s = nullptr;
+    ResultBlock* rb = nullptr;
     bool two = true;
 };
 template <typename T>
@@ -491,13 +507,14 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
-    if (scratch_alloc(ar, P.xy.sc, nx) || scratch_alloc(ar, P.yx.sc, ny)) return -1;
+    if (aalloc(ar, &P.rb, 1)) return -1;
+    if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
     if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
     P.xy.out_i = ext_cxy; P.yx.out_i = ext_cyx;
     if (!P.xy.out_i && aalloc(ar, &P.xy.out_i, (size_t)nx)) return -1;
     if (!P.yx.out_i && aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
-    if (aalloc(ar, &P.res_v, 4) || aalloc(ar, &P.res_ij, 8) || aalloc(ar, &P.res_s, 4)) return -1;
+    P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
     tm.mark(0);
     if (index_build(ix, P.dx, occ, s) || index_build(iy, P.dy, occ, s)) return -1;
     if (st) st->n_grid_builds += 2;
@@ -509,10 +526,13 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
 }
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
 template <typename T>
-static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
-    int r1 = search_finish(c, ar, s, P.xy, st);
+static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host) {
+    HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(host, c->h_pinned, sizeof(ResultBlock));
+    int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
     if (r1 < 0) return r1;
-    int r2 = P.two ? search_finish(c, ar, s, P.yx, st) : 0;
+    int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1]) : 0;
     if (r2 < 0) return r2;
     return (r1 | r2) ? 1 : 0;
 }
@@ -543,17 +563,16 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     do {
         PairState<T> P;
         if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided, max_leaf, !(flags & PCU_HIP_NO_TIE_ORDER)))) break;
-        T hv[2]; long long hij[4];
+        ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
             if (two_sided && (rc = argmax_enqueue(s, P.yx, P, 1))) break;
             tm.mark(3);
-            HIP_TRY(hipMemcpyAsync(hv, P.res_v, 2 * sizeof(T), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(hij, P.res_ij, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
-            else HIP_TRY(hipStreamSynchronize(s));
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
+            else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
         }
         if (rc) break;
+        const T* hv = reinterpret_cast<const T*>(host.vals); const long long* hij = host.ij;
         const int nres = two_sided ? 2 : 1;
         for (int r = 0; r < nres; ++r) { out_d[r] = hv[r]; out_i[r] = hij[2 * r]; out_j[r] = hij[2 * r + 1]; }
         if (st) { st->n_queries = two_sided ? nx + ny : nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
@@ -591,7 +610,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
         const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);
-        double hs[2];
+        ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
             hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.dx, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, pc, p_norm, P.pd);
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nbx, P.res_s + 0);
@@ -599,11 +618,11 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd + kRedBlocks, nby, P.res_s + 1);
             HIP_TRY(hipGetLastError());
             tm.mark(3);
-            HIP_TRY(hipMemcpyAsync(hs, P.res_s, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st); if (rc <= 0) break; rc = 0; }
-            else HIP_TRY(hipStreamSynchronize(s));
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host); if (rc <= 0) break; rc = 0; }
+            else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
         }
         if (rc) break;
+        const double* hs = host.sums;
         if (!on_dev) {
             if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.xy.out_i, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
             if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.yx.out_i, (size_t)ny * 8, hipMemcpyDeviceToHost, s));

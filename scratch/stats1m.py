@@ -1,0 +1,10 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+import point_cloud_utils_amd as pcu
+n = 1000000
+x = torch.from_numpy(np.random.default_rng(1000).random((n, 3), dtype=np.float32)).cuda()
+y = torch.from_numpy(np.random.default_rng(1001).random((n, 3), dtype=np.float32)).cuda()
+for i in range(3):
+    ch = pcu.chamfer_distance(x, y)
+    print(float(ch), pcu.last_stats())
+d, c = pcu.k_nearest_neighbors(x, y, 1); print(pcu.last_stats())

@@ -252,3 +252,18 @@ def test_gpu_kd_tree_is_nanoflanns_tree(pcu, dtype, leaf):
         assert rc == 0, _lib.last_error()
         assert nn.value == ni.shape[0], (name, nn.value, ni.shape[0])
         assert np.array_equal(vacc, vacc0), name
+
+
+def test_batched_single_rank(pcu, oracle_kind):
+    """BASELINE config 4 shape at reduced count: the batched driver on one rank, HIP path per pair."""
+    from point_cloud_utils_amd import batched
+
+    def get_pair(p):
+        return cloud(1000 + 2 * p, 20000, np.float32), cloud(1001 + 2 * p, 20000, np.float32)
+
+    hd = batched.batched_hausdorff(get_pair, 4)
+    ch = batched.batched_chamfer(get_pair, 4)
+    for p in range(4):
+        x, y = get_pair(p)
+        assert tuple(hd[p]) == oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind)
+        assert abs(ch[p] - float(oracle.chamfer_distance(x, y, kind=oracle_kind))) <= 1e-4 * ch[p]
