@@ -40,6 +40,7 @@ struct KdNode {
     int lt, le;                          // # elements < cutval, <= cutval
     int nbad[2];                         // misplaced pairs in planeSplit loop 1 / loop 2
     int chunk_base, nchunks;
+    int depth;
 };
 
 template <typename T>
@@ -53,7 +54,10 @@ struct KdBuild {
     int* n_items;
     int* chunk_bl; int* chunk_br;        // per work item: misplaced-left / misplaced-right counts, then offsets
     int* BLpos; int* BRpos;              // ranked positions, indexed by node.left + rank
+    int* sub_nodes; int* n_sub;          // nodes small enough to be finished inside one workgroup's LDS (k_kd_subtree)
+    int* max_depth;
     int leaf_max;
+    int sub_max;                         // nodes with <= sub_max elements go to sub_nodes
 };
 
 // Coordinate d of element p, read straight from memory at a computed offset. (A `d == 0 ? x : d == 1 ? y : z`
@@ -75,7 +79,7 @@ template <typename T>
 __device__ __forceinline__ void kd_node_init(KdNode<T>& nd, int left, int right) {
     nd.left = left; nd.right = right; nd.child1 = nd.child2 = -1; nd.divfeat = 0; nd.active = 0; nd.cutval = 0;
     for (int j = 0; j < 3; ++j) { nd.mm_lo[j] = ~(typename EncT<T>::type)0; nd.mm_hi[j] = 0; }
-    nd.lt = nd.le = 0; nd.nbad[0] = nd.nbad[1] = 0; nd.chunk_base = 0; nd.nchunks = 0;
+    nd.lt = nd.le = 0; nd.nbad[0] = nd.nbad[1] = 0; nd.chunk_base = 0; nd.nchunks = 0; nd.depth = 0;
 }
 
 // Root: bbox = exact min/max of the data (computeBoundingBox, nanoflann.hpp:1501-1536), taken from the grid
@@ -86,7 +90,9 @@ __global__ void k_kd_root(KdBuild<T> b, const GridParams<T>* gp, int n) {
     KdNode<T>& nd = b.nodes[0];
     kd_node_init(nd, 0, n);
     for (int j = 0; j < 3; ++j) { nd.bb_lo[j] = gp->gmin[j]; nd.bb_hi[j] = gp->gmax[j]; }
-    *b.n_nodes = 1; b.level_nodes[0] = 0; *b.n_next = 0;
+    *b.n_nodes = 1; *b.n_next = 0; *b.n_sub = 0; *b.max_depth = 0;
+    if (n <= b.sub_max) { b.sub_nodes[0] = 0; *b.n_sub = 1; *b.n_items = 0; b.level_nodes[0] = -1; }
+    else b.level_nodes[0] = 0;
 }
 
 // ---- per level: plan work items -------------------------------------------------------------------------------
@@ -214,18 +220,31 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
     if (threadIdx.x == 0) { b.chunk_bl[wi] = (int)tl; b.chunk_br[wi] = (int)tr; }
 }
 
-// ---- K5: per node, chunk offsets: misplaced-left ranks count from the left, misplaced-right ranks from the right
+// ---- K5: per node (one block each), chunk offsets: misplaced-left ranks count from the left, misplaced-right ranks
+// from the right end of the node
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_kd_chunk_scan(KdBuild<T> b, int n_level, int ph) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_level) return;
-    KdNode<T>& nd = b.nodes[b.level_nodes[i]];
+    if ((int)blockIdx.x >= n_level) return;
+    KdNode<T>& nd = b.nodes[b.level_nodes[blockIdx.x]];
     if (!nd.active) return;
-    int run = 0;
-    for (int c = 0; c < nd.nchunks; ++c) { const int t = b.chunk_bl[nd.chunk_base + c]; b.chunk_bl[nd.chunk_base + c] = run; run += t; }
-    int rrun = 0;
-    for (int c = nd.nchunks - 1; c >= 0; --c) { const int t = b.chunk_br[nd.chunk_base + c]; b.chunk_br[nd.chunk_base + c] = rrun; rrun += t; }
-    nd.nbad[ph] = run;      // == rrun: both cursors stop together
+    int* cbl = b.chunk_bl + nd.chunk_base; int* cbr = b.chunk_br + nd.chunk_base;
+    const int nc = nd.nchunks;
+    unsigned tot_r = 0;
+    for (int base = 0; base < nc; base += kBlock) {           // total of misplaced-right first
+        const int c = base + threadIdx.x;
+        unsigned t; block_exclusive_scan(c < nc ? (unsigned)cbr[c] : 0u, &t);
+        tot_r += t;
+    }
+    unsigned carry_l = 0, carry_r = 0;
+    for (int base = 0; base < nc; base += kBlock) {
+        const int c = base + threadIdx.x;
+        const unsigned vl = c < nc ? (unsigned)cbl[c] : 0u, vr = c < nc ? (unsigned)cbr[c] : 0u;
+        unsigned tl, tr;
+        const unsigned el = block_exclusive_scan(vl, &tl), er = block_exclusive_scan(vr, &tr);
+        if (c < nc) { cbl[c] = (int)(carry_l + el); cbr[c] = (int)(tot_r - (carry_r + er) - vr); }   // # misplaced-right in chunks to the right
+        carry_l += tl; carry_r += tr;
+    }
+    if (threadIdx.x == 0) nd.nbad[ph] = (int)carry_l;      // == tot_r: both cursors stop together
 }
 
 // ---- K6: ranked position lists. Thread t owns kKdItems consecutive positions so ranks follow position order.
@@ -293,8 +312,252 @@ __global__ __launch_bounds__(kBlock) void k_kd_split(KdBuild<T> b, int n_level) 
     l.bb_hi[nd.divfeat] = nd.cutval;
     r.bb_lo[nd.divfeat] = nd.cutval;
     nd.child1 = c; nd.child2 = c + 1; nd.active = 0;
-    const int o = atomicAdd(b.n_next, 2);
-    b.next_nodes[o] = c; b.next_nodes[o + 1] = c + 1;
+    l.depth = r.depth = nd.depth + 1;
+    atomicMax(b.max_depth, nd.depth + 1);
+    for (int k = 0; k < 2; ++k) {
+        const int id2 = c + k; const KdNode<T>& ch = k ? r : l;
+        if (ch.right - ch.left <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = id2;     // finished in LDS later
+        else b.next_nodes[atomicAdd(b.n_next, 1)] = id2;
+    }
+}
+
+// ---- sub-trees in LDS -------------------------------------------------------------------------------------------------
+// One workgroup takes a node of <= S elements, copies the elements into LDS and runs the *same* level-by-level
+// algorithm there (choose / count / ranked misplaced lists / pairwise swap, twice / split / children boxes) with
+// __syncthreads() in place of kernel boundaries, then writes the permuted elements back. This removes the many
+// launches over ever smaller nodes that dominate a purely level-synchronous build (the last ~15 of ~25 levels).
+template <typename T> struct KdSub;
+template <> struct KdSub<float>  { static constexpr int S = 4096, CAP = 384; };
+template <> struct KdSub<double> { static constexpr int S = 2048, CAP = 256; };
+constexpr int kSubThreads = 512;
+
+template <typename T>
+__host__ __device__ constexpr size_t kd_sub_lds_bytes() {
+    typedef typename EncT<T>::type Enc;
+    return (size_t)KdSub<T>::S * sizeof(Pt4<T>) + 3 * (size_t)KdSub<T>::S * 2 + 13 * (size_t)KdSub<T>::CAP * 4 + (size_t)KdSub<T>::CAP * sizeof(T) +
+           18 * (size_t)KdSub<T>::CAP * sizeof(Enc) + 2 * (size_t)KdSub<T>::CAP * 2 + 256;
+}
+
+__device__ __forceinline__ void block_scan2_512(unsigned a, unsigned b2, unsigned& ea, unsigned& eb, unsigned& ta, unsigned& tb, unsigned* s_w /*34 words*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned ia = a, ib = b2;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned x = __shfl_up(ia, o, 64), y = __shfl_up(ib, o, 64); if (lane >= o) { ia += x; ib += y; } }
+    if (lane == 63) { s_w[wave] = ia; s_w[16 + wave] = ib; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned ra = 0, rb = 0;
+        for (int w = 0; w < kSubThreads / 64; ++w) { unsigned x = s_w[w], y = s_w[16 + w]; s_w[w] = ra; s_w[16 + w] = rb; ra += x; rb += y; }
+        s_w[32] = ra; s_w[33] = rb;
+    }
+    __syncthreads();
+    ea = ia - a + s_w[wave]; eb = ib - b2 + s_w[16 + wave]; ta = s_w[32]; tb = s_w[33];
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
+    typedef typename EncT<T>::type Enc;
+    constexpr int S = KdSub<T>::S, CAP = KdSub<T>::CAP, IPT = S / kSubThreads;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Pt4<T>* E = reinterpret_cast<Pt4<T>*>(smem);
+    unsigned short* seg = reinterpret_cast<unsigned short*>(E + S);
+    unsigned short* BL = seg + S; unsigned short* BR = BL + S;
+    int* n_gid = reinterpret_cast<int*>(BR + S);
+    int* n_left = n_gid + CAP; int* n_right = n_left + CAP; int* n_feat = n_right + CAP; int* n_lt = n_feat + CAP; int* n_le = n_lt + CAP;
+    int* n_pbl0 = n_le + CAP; int* n_pbl1 = n_pbl0 + CAP; int* n_pbr1 = n_pbl1 + CAP; int* n_idx = n_pbr1 + CAP;
+    int* x_gid = n_idx + CAP; int* x_left = x_gid + CAP; int* x_right = x_left + CAP;   // next level's nodes
+    T* n_cut = reinterpret_cast<T*>(x_right + CAP);
+    Enc* cur_mm = reinterpret_cast<Enc*>(n_cut + CAP);                         // [CAP][6]
+    Enc* c_mm = cur_mm + 6 * CAP;                                              // [2*CAP][6]
+    unsigned short* child_slot = reinterpret_cast<unsigned short*>(c_mm + 12 * CAP);   // [2*CAP]
+    unsigned* s_w = reinterpret_cast<unsigned*>(child_slot + 2 * CAP);        // 34 words scan scratch + misc
+    int* s_misc = reinterpret_cast<int*>(s_w + 40);                            // [0]=n_next [1]=id base
+
+    const int root_gid = b.sub_nodes[blockIdx.x];
+    KdNode<T>& root = b.nodes[root_gid];
+    const int g0 = root.left, n = root.right - root.left;
+    const int tid = threadIdx.x;
+    for (int p = tid; p < n; p += kSubThreads) { E[p] = b.E[g0 + p]; seg[p] = 0; }
+    for (int p = n + tid; p < S; p += kSubThreads) seg[p] = 0xFFFF;
+    if (tid < 6) cur_mm[tid] = tid < 3 ? ~(Enc)0 : (Enc)0;
+    if (tid == 0) { n_gid[0] = root_gid; n_left[0] = 0; n_right[0] = n; }
+    __syncthreads();
+    {   // tight box of the sub-root (computeMinMax); wave pre-reduction, then LDS atomics
+        T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+        for (int p = tid; p < n; p += kSubThreads) {
+            const Pt4<T> v = E[p];
+            lo[0] = v.x < lo[0] ? v.x : lo[0]; hi[0] = v.x > hi[0] ? v.x : hi[0];
+            lo[1] = v.y < lo[1] ? v.y : lo[1]; hi[1] = v.y > hi[1] ? v.y : hi[1];
+            lo[2] = v.z < lo[2] ? v.z : lo[2]; hi[2] = v.z > hi[2] ? v.z : hi[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const T a = wave_min(lo[j]), c = wave_max(hi[j]);
+            if ((tid & 63) == 0 && a <= c) { atomicMin(&cur_mm[j], enc(a)); atomicMax(&cur_mm[3 + j], enc(c)); }
+        }
+    }
+    __syncthreads();
+    if (tid < 3) { root.mm_lo[tid] = cur_mm[tid]; root.mm_hi[tid] = cur_mm[3 + tid]; }
+    int n_act = (n > b.leaf_max) ? 1 : 0;
+    const int p0 = tid * IPT;                       // this thread's contiguous positions [p0, p0+IPT)
+
+    while (n_act > 0) {
+        // S1: leaf test is implied (only nodes with count > leaf_max are active); middleSplit_ head
+        if (tid < n_act) {
+            KdNode<T>& nd = b.nodes[n_gid[tid]];
+            const T EPS = (T)0.00001;
+            T max_span = nd.bb_hi[0] - nd.bb_lo[0];
+            for (int d = 1; d < 3; ++d) { const T span = nd.bb_hi[d] - nd.bb_lo[d]; if (span > max_span) max_span = span; }
+            T max_spread = -1; int cutfeat = 0;
+            for (int d = 0; d < 3; ++d) {
+                const T span = nd.bb_hi[d] - nd.bb_lo[d];
+                if (span > ((T)1 - EPS) * max_span) {
+                    const T spread = dec(cur_mm[6 * tid + 3 + d]) - dec(cur_mm[6 * tid + d]);
+                    if (spread > max_spread) { cutfeat = d; max_spread = spread; }
+                }
+            }
+            const T split_val = (nd.bb_lo[cutfeat] + nd.bb_hi[cutfeat]) / (T)2;
+            const T mn = dec(cur_mm[6 * tid + cutfeat]), mx = dec(cur_mm[6 * tid + 3 + cutfeat]);
+            T cutval;
+            if (split_val < mn) cutval = mn; else if (split_val > mx) cutval = mx; else cutval = split_val;
+            nd.divfeat = cutfeat; nd.cutval = cutval;
+            n_feat[tid] = cutfeat; n_cut[tid] = cutval; n_lt[tid] = 0; n_le[tid] = 0;
+        }
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        // S2: lim1, lim2
+        for (int p = tid; p < n; p += kSubThreads) {
+            const int i = seg[p];
+            if (i == 0xFFFF) continue;
+            const T v = reinterpret_cast<const T*>(E + p)[n_feat[i]];
+            if (v < n_cut[i]) atomicAdd(&n_lt[i], 1);
+            if (v <= n_cut[i]) atomicAdd(&n_le[i], 1);
+        }
+        __syncthreads();
+        // S3/S4 twice: ranked misplaced lists + pairwise swap (planeSplit loops 1 and 2)
+        for (int ph = 0; ph < 2; ++ph) {
+            bool bl[IPT], br[IPT];
+            unsigned nl = 0, nr = 0;
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int p = p0 + j;
+                bl[j] = br[j] = false;
+                const int i = p < n ? seg[p] : 0xFFFF;
+                if (i != 0xFFFF) {
+                    const T v = reinterpret_cast<const T*>(E + p)[n_feat[i]];
+                    const int lo = ph == 0 ? n_left[i] : n_left[i] + n_lt[i];
+                    const int lim = ph == 0 ? n_left[i] + n_lt[i] : n_left[i] + n_le[i];
+                    const bool good = ph == 0 ? (v < n_cut[i]) : (v <= n_cut[i]);
+                    bl[j] = p >= lo && p < lim && !good;
+                    br[j] = p >= lim && good;
+                }
+                nl += bl[j]; nr += br[j];
+            }
+            unsigned el, er, tl, tr;
+            block_scan2_512(nl, nr, el, er, tl, tr, s_w);
+            {   // record the prefixes at node boundaries
+                unsigned rl = el, rr = er;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const int p = p0 + j;
+                    const int i = p < n ? seg[p] : 0xFFFF;
+                    if (i != 0xFFFF) {
+                        if (p == n_left[i]) n_pbl0[i] = (int)rl;
+                        if (p == n_right[i] - 1) { n_pbl1[i] = (int)(rl + bl[j]); n_pbr1[i] = (int)(rr + br[j]); }
+                    }
+                    rl += bl[j]; rr += br[j];
+                }
+            }
+            __syncthreads();
+            {
+                unsigned rl = el, rr = er;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const int p = p0 + j;
+                    const int i = p < n ? seg[p] : 0xFFFF;
+                    if (i != 0xFFFF) {
+                        if (bl[j]) BL[n_left[i] + ((int)rl - n_pbl0[i])] = (unsigned short)p;
+                        if (br[j]) BR[n_left[i] + (n_pbr1[i] - 1 - (int)rr)] = (unsigned short)p;
+                    }
+                    rl += bl[j]; rr += br[j];
+                }
+            }
+            __syncthreads();
+            for (int x = tid; x < n; x += kSubThreads) {
+                const int i = seg[x];
+                if (i == 0xFFFF) continue;
+                const int j = x - n_left[i];
+                if (j < n_pbl1[i] - n_pbl0[i]) {
+                    const int pl = BL[n_left[i] + j], pr = BR[n_left[i] + j];
+                    const Pt4<T> a = E[pl], c = E[pr];
+                    E[pl] = c; E[pr] = a;
+                }
+            }
+            __syncthreads();
+        }
+        // S5: split index, children
+        if (tid == 0) s_misc[1] = atomicAdd(b.n_nodes, 2 * n_act);
+        __syncthreads();
+        if (tid < n_act) {
+            const int gid = n_gid[tid];
+            KdNode<T>& nd = b.nodes[gid];
+            const int count = n_right[tid] - n_left[tid], lim1 = n_lt[tid], lim2 = n_le[tid];
+            int index;
+            if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
+            n_idx[tid] = index;
+            const int c = s_misc[1] + 2 * tid;
+            KdNode<T>& l = b.nodes[c]; KdNode<T>& r = b.nodes[c + 1];
+            kd_node_init(l, g0 + n_left[tid], g0 + n_left[tid] + index);
+            kd_node_init(r, g0 + n_left[tid] + index, g0 + n_right[tid]);
+            for (int j = 0; j < 3; ++j) { l.bb_lo[j] = r.bb_lo[j] = nd.bb_lo[j]; l.bb_hi[j] = r.bb_hi[j] = nd.bb_hi[j]; }
+            l.bb_hi[nd.divfeat] = nd.cutval; r.bb_lo[nd.divfeat] = nd.cutval;
+            l.depth = r.depth = nd.depth + 1;
+            nd.child1 = c; nd.child2 = c + 1;
+            atomicMax(b.max_depth, nd.depth + 1);
+            for (int k = 0; k < 2; ++k) {
+                const int cl = k ? n_left[tid] + index : n_left[tid], cr = k ? n_right[tid] : n_left[tid] + index;
+                for (int j = 0; j < 3; ++j) { c_mm[6 * (2 * tid + k) + j] = ~(Enc)0; c_mm[6 * (2 * tid + k) + 3 + j] = 0; }
+                if (cr - cl > b.leaf_max) {
+                    const int slot = atomicAdd(&s_misc[0], 1);
+                    x_gid[slot] = c + k; x_left[slot] = cl; x_right[slot] = cr;
+                    child_slot[2 * tid + k] = (unsigned short)slot;
+                } else child_slot[2 * tid + k] = 0xFFFF;
+            }
+        }
+        __syncthreads();
+        // S6: children's tight boxes + re-label elements
+        for (int p = tid; p < n; p += kSubThreads) {
+            const int i = seg[p];
+            if (i == 0xFFFF) continue;
+            const int k = p >= n_left[i] + n_idx[i];
+            const Pt4<T> v = E[p];
+            Enc* mm = c_mm + 6 * (2 * i + k);
+            atomicMin(&mm[0], enc(v.x)); atomicMax(&mm[3], enc(v.x));
+            atomicMin(&mm[1], enc(v.y)); atomicMax(&mm[4], enc(v.y));
+            atomicMin(&mm[2], enc(v.z)); atomicMax(&mm[5], enc(v.z));
+            seg[p] = child_slot[2 * i + k];
+        }
+        __syncthreads();
+        // S7: publish children's boxes; install the next level
+        const int n_next = s_misc[0];
+        for (int cidx = tid; cidx < 2 * n_act; cidx += kSubThreads) {
+            KdNode<T>& ch = b.nodes[s_misc[1] + cidx];
+            for (int j = 0; j < 3; ++j) { ch.mm_lo[j] = c_mm[6 * cidx + j]; ch.mm_hi[j] = c_mm[6 * cidx + 3 + j]; }
+        }
+        __syncthreads();
+        for (int cidx = tid; cidx < 2 * n_act; cidx += kSubThreads) {
+            const int slot = child_slot[cidx];
+            if (slot != 0xFFFF) for (int j = 0; j < 6; ++j) cur_mm[6 * slot + j] = c_mm[6 * cidx + j];
+        }
+        int xg = 0, xl = 0, xr = 0;
+        if (tid < n_next) { xg = x_gid[tid]; xl = x_left[tid]; xr = x_right[tid]; }
+        __syncthreads();
+        if (tid < n_next) { n_gid[tid] = xg; n_left[tid] = xl; n_right[tid] = xr; }
+        n_act = n_next;
+        __syncthreads();
+    }
+    for (int p = tid; p < n; p += kSubThreads) b.E[g0 + p] = E[p];
 }
 
 // ---- nanoflann search for the tied queries ---------------------------------------------------------------------------

@@ -259,13 +259,16 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     if (aalloc(ar, &b.item_node, max_items) || aalloc(ar, &b.item_chunk, max_items)) return -1;
     if (aalloc(ar, &b.chunk_bl, max_items) || aalloc(ar, &b.chunk_br, max_items)) return -1;
     if (aalloc(ar, &b.BLpos, (size_t)M) || aalloc(ar, &b.BRpos, (size_t)M)) return -1;
+    if (aalloc(ar, &b.sub_nodes, max_level)) return -1;
     b.n_nodes = counters; b.n_next = counters + 1; b.n_items = counters + 2;
     *err_out = counters + 3;
+    b.n_sub = counters + 4; b.max_depth = counters + 5;
     b.leaf_max = leaf_max;
+    b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
-    int n_level = 1, level_count = 0;
+    int n_level = M > b.sub_max ? 1 : 0, level_count = 0;
     const bool dbg = getenv("PCU_HIP_DEBUG_KD") != nullptr;
     for (int level = 0; n_level > 0; ++level) {
         if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
@@ -278,7 +281,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
         for (int ph = 0; ph < 2; ++ph) {
             KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-            KD_STEP("chunk_scan", hipLaunchKernelGGL(k_kd_chunk_scan<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level, ph));
+            KD_STEP("chunk_scan", hipLaunchKernelGGL(k_kd_chunk_scan<T>, dim3(n_level), dim3(kBlock), 0, s, b, n_level, ph));
             KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
             KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
         }
@@ -292,8 +295,25 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         n_level = n_next;
         level_count = level + 1;
     }
-    (void)c;
-    *levels_out = level_count;
+    (void)c; (void)level_count;
+    // finish every small node inside one workgroup's LDS
+    int hcnt[8];
+    HIP_TRY(hipMemcpyAsync(hcnt, b.n_nodes, sizeof hcnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int n_sub = hcnt[4];
+    if (n_sub > 0) {
+        static bool attr_set[2] = {false, false};
+        const int ti = sizeof(T) == 4 ? 0 : 1;
+        if (!attr_set[ti]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_subtree<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kd_sub_lds_bytes<T>()));
+            attr_set[ti] = true;
+        }
+        hipLaunchKernelGGL(k_kd_subtree<T>, dim3(n_sub), dim3(kSubThreads), kd_sub_lds_bytes<T>(), s, b);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(hcnt, b.n_nodes, sizeof hcnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *levels_out = hcnt[5] + 1;      // tree depth (root = 0) + 1
     return 0;
 }
 

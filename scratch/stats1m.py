@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import point_cloud_utils_amd as pcu
 n = 1000000
 x = torch.from_numpy(np.random.default_rng(1000).random((n, 3), dtype=np.float32)).cuda()
