@@ -30,6 +30,8 @@ __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_dis
            "last_stats", "set_cell_occupancy", "device_count"]
 
 _last_stats = {}
+# PCU_HIP_NO_TIE_ORDER=1: skip the kd-tree tie-order resolver (exact ties then ordered by (d2, row)); for experiments.
+_ENV_FLAGS = _lib.NO_TIE_ORDER if __import__("os").environ.get("PCU_HIP_NO_TIE_ORDER", "0") not in ("", "0") else 0
 
 
 def last_stats():
@@ -95,7 +97,7 @@ class _Dev:
             self.device = a.device.index if a.device.index is not None else torch.cuda.current_device()
             self.tdev = a.device
             self.stream = torch.cuda.current_stream(a.device).cuda_stream
-            self.flags = _lib.PTRS_ON_DEVICE
+            self.flags = _lib.PTRS_ON_DEVICE | _ENV_FLAGS
             self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
             self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64
             self.t_dtype = a.dtype
@@ -103,7 +105,7 @@ class _Dev:
             self.a, self.b = np.ascontiguousarray(a), np.ascontiguousarray(b)
             self.device = _lib.default_device()
             self.stream = None
-            self.flags = 0
+            self.flags = _ENV_FLAGS
             self.pa, self.pb = self.a.ctypes.data, self.b.ctypes.data
             self.np_dtype = self.a.dtype.type
         self.suffix = "f32" if self.np_dtype == np.float32 else "f64"

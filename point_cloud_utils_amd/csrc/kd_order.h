@@ -33,7 +33,7 @@ struct KdNode {
     int left, right;                     // element range [left, right)
     int child1, child2;                  // node ids; -1 = leaf
     int divfeat;
-    int active;                          // 1 while the node still has to be split at the current level
+    int active;                          // (unused)
     T cutval;
     T bb_lo[3], bb_hi[3];                // the bbox handed DOWN to divideTree (input to middleSplit_)
     typename EncT<T>::type mm_lo[3], mm_hi[3];   // tight min/max of the node's points (encoded, atomics); = computeMinMax
@@ -50,7 +50,7 @@ struct KdBuild {
     int* n_nodes;                        // device counter
     int* level_nodes;                    // node ids of the current level
     int* next_nodes; int* n_next;        // node ids created for the next level
-    int* item_node; int* item_chunk;     // work items
+    int* level_cbase; int* next_cbase;   // exclusive prefix of chunk counts over the level's nodes (+ total)
     int* n_items;
     int* chunk_bl; int* chunk_br;        // per work item: misplaced-left / misplaced-right counts, then offsets
     int* BLpos; int* BRpos;              // ranked positions, indexed by node.left + rank
@@ -92,40 +92,27 @@ __global__ void k_kd_root(KdBuild<T> b, const GridParams<T>* gp, int n) {
     for (int j = 0; j < 3; ++j) { nd.bb_lo[j] = gp->gmin[j]; nd.bb_hi[j] = gp->gmax[j]; }
     *b.n_nodes = 1; *b.n_next = 0; *b.n_sub = 0; *b.max_depth = 0;
     if (n <= b.sub_max) { b.sub_nodes[0] = 0; *b.n_sub = 1; *b.n_items = 0; b.level_nodes[0] = -1; }
-    else b.level_nodes[0] = 0;
+    else { b.level_nodes[0] = 0; b.level_cbase[0] = 0; b.level_cbase[1] = (n + kKdChunk - 1) / kKdChunk; *b.n_items = b.level_cbase[1]; }
 }
 
-// ---- per level: plan work items -------------------------------------------------------------------------------
-// One block: chunk counts of the level's nodes -> exclusive scan -> (node, chunk) work-item table.
+// ---- per level (nodes too large for one workgroup): 9 launches -------------------------------------------------
+// Work items are (node, chunk) pairs; a block finds its pair by a binary search in the level's chunk-prefix table.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_plan(KdBuild<T> b, int n_level) {
-    __shared__ unsigned s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_level; base += kBlock) {
-        const int i = base + threadIdx.x;
-        unsigned nc = 0; int id = -1;
-        if (i < n_level) { id = b.level_nodes[i]; const KdNode<T>& nd = b.nodes[id]; nc = (unsigned)((nd.right - nd.left + kKdChunk - 1) / kKdChunk); }
-        unsigned total;
-        const unsigned ex = block_exclusive_scan(nc, &total) + s_carry;
-        if (id >= 0) {
-            b.nodes[id].chunk_base = (int)ex; b.nodes[id].nchunks = (int)nc;
-            for (unsigned c = 0; c < nc; ++c) { b.item_node[ex + c] = id; b.item_chunk[ex + c] = (int)c; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { *b.n_items = (int)s_carry; *b.n_next = 0; }
+__device__ __forceinline__ bool kd_locate(const KdBuild<T>& b, int n_level, int wi, int& node_id, int& chunk) {
+    if (wi >= *b.n_items) return false;
+    int lo = 0, hi = n_level;                         // level_cbase[lo] <= wi < level_cbase[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.level_cbase[mid] <= wi) lo = mid; else hi = mid; }
+    node_id = b.level_nodes[lo]; chunk = wi - b.level_cbase[lo];
+    return true;
 }
 
-// ---- K1: tight min/max of every node of the level (leaves included: their boxes give the parents' divlow/divhigh)
+// K1: tight min/max (computeMinMax) of every node of the level
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b) {
-    const int wi = blockIdx.x;
-    if (wi >= *b.n_items) return;
-    KdNode<T>& nd = b.nodes[b.item_node[wi]];
-    const int s = nd.left + b.item_chunk[wi] * kKdChunk, e = min(s + kKdChunk, nd.right);
+__global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b, int n_level) {
+    int id, chunk;
+    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    KdNode<T>& nd = b.nodes[id];
+    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     for (int p = s + threadIdx.x; p < e; p += kBlock) {
@@ -150,41 +137,39 @@ __global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b) {
     }
 }
 
-// ---- K2: leaf test + middleSplit_ head (nanoflann.hpp:1008, :1061-1099): cut dimension and cut value
+// middleSplit_ head (nanoflann.hpp:1061-1099): cut dimension and cut value from the hand-down box and the tight box.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_choose(KdBuild<T> b, int n_level) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_level) return;
-    KdNode<T>& nd = b.nodes[b.level_nodes[i]];
-    const int count = nd.right - nd.left;
-    if (count <= b.leaf_max) { nd.active = 0; return; }           // (right - left) <= leaf_max_size -> leaf
+__device__ __forceinline__ void kd_choose(const T* bb_lo, const T* bb_hi, const T* mn, const T* mx, int& cutfeat_out, T& cutval_out) {
     const T EPS = (T)0.00001;
-    T max_span = nd.bb_hi[0] - nd.bb_lo[0];
-    for (int d = 1; d < 3; ++d) { const T span = nd.bb_hi[d] - nd.bb_lo[d]; if (span > max_span) max_span = span; }
+    T max_span = bb_hi[0] - bb_lo[0];
+    for (int d = 1; d < 3; ++d) { const T span = bb_hi[d] - bb_lo[d]; if (span > max_span) max_span = span; }
     T max_spread = -1; int cutfeat = 0;
     for (int d = 0; d < 3; ++d) {
-        const T span = nd.bb_hi[d] - nd.bb_lo[d];
+        const T span = bb_hi[d] - bb_lo[d];
         if (span > ((T)1 - EPS) * max_span) {
-            const T spread = dec(nd.mm_hi[d]) - dec(nd.mm_lo[d]);
+            const T spread = mx[d] - mn[d];
             if (spread > max_spread) { cutfeat = d; max_spread = spread; }
         }
     }
-    const T split_val = (nd.bb_lo[cutfeat] + nd.bb_hi[cutfeat]) / (T)2;
-    const T mn = dec(nd.mm_lo[cutfeat]), mx = dec(nd.mm_hi[cutfeat]);
+    const T split_val = (bb_lo[cutfeat] + bb_hi[cutfeat]) / (T)2;
     T cutval;
-    if (split_val < mn) cutval = mn; else if (split_val > mx) cutval = mx; else cutval = split_val;
-    nd.divfeat = cutfeat; nd.cutval = cutval; nd.active = 1; nd.lt = 0; nd.le = 0; nd.nbad[0] = nd.nbad[1] = 0;
+    if (split_val < mn[cutfeat]) cutval = mn[cutfeat]; else if (split_val > mx[cutfeat]) cutval = mx[cutfeat]; else cutval = split_val;
+    cutfeat_out = cutfeat; cutval_out = cutval;
 }
 
-// ---- K3: lim1 - left = #(< cutval), lim2 - left = #(<= cutval)
+// K2: every block re-derives its node's cut (cheap scalar work, saves a launch), chunk 0 records it;
+//     lim1 - left = #(< cutval), lim2 - left = #(<= cutval)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b) {
-    const int wi = blockIdx.x;
-    if (wi >= *b.n_items) return;
-    KdNode<T>& nd = b.nodes[b.item_node[wi]];
-    if (!nd.active) return;
-    const int s = nd.left + b.item_chunk[wi] * kKdChunk, e = min(s + kKdChunk, nd.right);
-    const int f = nd.divfeat; const T cut = nd.cutval;
+__global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b, int n_level) {
+    int id, chunk;
+    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    KdNode<T>& nd = b.nodes[id];
+    T mn[3], mx[3];
+    for (int j = 0; j < 3; ++j) { mn[j] = dec(nd.mm_lo[j]); mx[j] = dec(nd.mm_hi[j]); }
+    int f; T cut;
+    kd_choose(nd.bb_lo, nd.bb_hi, mn, mx, f, cut);
+    if (chunk == 0 && threadIdx.x == 0) { nd.divfeat = f; nd.cutval = cut; }
+    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     unsigned lt = 0, le = 0;
     for (int p = s + threadIdx.x; p < e; p += kBlock) { const T v = kd_coord(b.E, p, f); lt += v < cut; le += v <= cut; }
     unsigned tl, te;
@@ -202,14 +187,16 @@ __device__ __forceinline__ void kd_flags(const KdNode<T>& nd, int ph, int p, T v
     bad_right = p >= lim && good;
 }
 
-// ---- K4: per work item counts of misplaced-left / misplaced-right
+// K3: per work item counts of misplaced-left / misplaced-right. Loop 2 has nothing to do when no element equals
+// the cut value (lt == le): its three launches then exit at once.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
+__global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int n_level, int ph) {
+    int id, chunk;
+    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    KdNode<T>& nd = b.nodes[id];
     const int wi = blockIdx.x;
-    if (wi >= *b.n_items) return;
-    KdNode<T>& nd = b.nodes[b.item_node[wi]];
-    if (!nd.active) return;
-    const int s = nd.left + b.item_chunk[wi] * kKdChunk, e = min(s + kKdChunk, nd.right);
+    if (ph == 1 && nd.lt == nd.le) { if (threadIdx.x == 0) { b.chunk_bl[wi] = 0; b.chunk_br[wi] = 0; } return; }
+    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     unsigned nl = 0, nr = 0;
     for (int p = s + threadIdx.x; p < e; p += kBlock) {
         bool bl, br; kd_flags(nd, ph, p, kd_coord(b.E, p, nd.divfeat), bl, br);
@@ -220,41 +207,25 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
     if (threadIdx.x == 0) { b.chunk_bl[wi] = (int)tl; b.chunk_br[wi] = (int)tr; }
 }
 
-// ---- K5: per node (one block each), chunk offsets: misplaced-left ranks count from the left, misplaced-right ranks
-// from the right end of the node
+// K4: ranked position lists. A block first folds its node's chunk counts into its own offsets (misplaced-left
+// ranks count from the node's left end, misplaced-right ranks from its right end). Thread t owns kKdItems
+// consecutive positions so ranks follow position order.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_chunk_scan(KdBuild<T> b, int n_level, int ph) {
-    if ((int)blockIdx.x >= n_level) return;
-    KdNode<T>& nd = b.nodes[b.level_nodes[blockIdx.x]];
-    if (!nd.active) return;
-    int* cbl = b.chunk_bl + nd.chunk_base; int* cbr = b.chunk_br + nd.chunk_base;
-    const int nc = nd.nchunks;
-    unsigned tot_r = 0;
-    for (int base = 0; base < nc; base += kBlock) {           // total of misplaced-right first
-        const int c = base + threadIdx.x;
-        unsigned t; block_exclusive_scan(c < nc ? (unsigned)cbr[c] : 0u, &t);
-        tot_r += t;
+__global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int n_level, int ph) {
+    int id, chunk;
+    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    KdNode<T>& nd = b.nodes[id];
+    if (ph == 1 && nd.lt == nd.le) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[1] = 0; return; }
+    const int wi = blockIdx.x, wi0 = wi - chunk, nc = (nd.right - nd.left + kKdChunk - 1) / kKdChunk;
+    unsigned before_l = 0, after_r = 0, all_l = 0;
+    for (int c = threadIdx.x; c < nc; c += kBlock) {
+        const unsigned vl = (unsigned)b.chunk_bl[wi0 + c], vr = (unsigned)b.chunk_br[wi0 + c];
+        all_l += vl; if (c < chunk) before_l += vl; if (c > chunk) after_r += vr;
     }
-    unsigned carry_l = 0, carry_r = 0;
-    for (int base = 0; base < nc; base += kBlock) {
-        const int c = base + threadIdx.x;
-        const unsigned vl = c < nc ? (unsigned)cbl[c] : 0u, vr = c < nc ? (unsigned)cbr[c] : 0u;
-        unsigned tl, tr;
-        const unsigned el = block_exclusive_scan(vl, &tl), er = block_exclusive_scan(vr, &tr);
-        if (c < nc) { cbl[c] = (int)(carry_l + el); cbr[c] = (int)(tot_r - (carry_r + er) - vr); }   // # misplaced-right in chunks to the right
-        carry_l += tl; carry_r += tr;
-    }
-    if (threadIdx.x == 0) nd.nbad[ph] = (int)carry_l;      // == tot_r: both cursors stop together
-}
-
-// ---- K6: ranked position lists. Thread t owns kKdItems consecutive positions so ranks follow position order.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
-    const int wi = blockIdx.x;
-    if (wi >= *b.n_items) return;
-    KdNode<T>& nd = b.nodes[b.item_node[wi]];
-    if (!nd.active) return;
-    const int s = nd.left + b.item_chunk[wi] * kKdChunk, e = min(s + kKdChunk, nd.right);
+    unsigned t_bl, t_ar, t_all;
+    block_exclusive_scan(before_l, &t_bl); block_exclusive_scan(after_r, &t_ar); block_exclusive_scan(all_l, &t_all);
+    if (chunk == 0 && threadIdx.x == 0) nd.nbad[ph] = (int)t_all;
+    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     bool bl[kKdItems], br[kKdItems];
     unsigned nl = 0, nr = 0;
     const int p0 = s + threadIdx.x * kKdItems;
@@ -268,8 +239,8 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
     unsigned tl, tr;
     unsigned el = block_exclusive_scan(nl, &tl);
     unsigned er = block_exclusive_scan(nr, &tr);
-    const int base_l = nd.left + b.chunk_bl[wi];
-    const int base_r = nd.left + b.chunk_br[wi];
+    const int base_l = nd.left + (int)t_bl;
+    const int base_r = nd.left + (int)t_ar;
 #pragma unroll
     for (int j = 0; j < kKdItems; ++j) {
         const int p = p0 + j;
@@ -278,14 +249,13 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
     }
 }
 
-// ---- K7: swap the j-th misplaced-left with the j-th misplaced-right (std::swap in planeSplit, :1137 / :1155)
+// K5: swap the j-th misplaced-left with the j-th misplaced-right (std::swap in planeSplit, :1137 / :1155)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int ph) {
-    const int wi = blockIdx.x;
-    if (wi >= *b.n_items) return;
-    KdNode<T>& nd = b.nodes[b.item_node[wi]];
-    if (!nd.active) return;
-    const int j0 = b.item_chunk[wi] * kKdChunk, nb = nd.nbad[ph];
+__global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int n_level, int ph) {
+    int id, chunk;
+    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    KdNode<T>& nd = b.nodes[id];
+    const int j0 = chunk * kKdChunk, nb = nd.nbad[ph];
     for (int j = j0 + threadIdx.x; j < min(j0 + kKdChunk, nb); j += kBlock) {
         const int pl = b.BLpos[nd.left + j], pr = b.BRpos[nd.left + j];
         const Pt4<T> a = b.E[pl], c = b.E[pr];
@@ -293,32 +263,51 @@ __global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int ph) {
     }
 }
 
-// ---- K8: split index (middleSplit_ tail, :1104-1109) and the two children with their hand-down boxes (:1040-1046)
+// K6 (one block): split index (middleSplit_ tail, :1104-1109), the two children with their hand-down boxes
+// (:1040-1046), routing of each child (next level / LDS sub-tree list), and the next level's chunk-prefix table.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_split(KdBuild<T> b, int n_level) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_level) return;
-    const int id = b.level_nodes[i];
-    KdNode<T>& nd = b.nodes[id];
-    if (!nd.active) return;
-    const int count = nd.right - nd.left, lim1 = nd.lt, lim2 = nd.le;
-    int index;
-    if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
-    const int c = atomicAdd(b.n_nodes, 2);
-    KdNode<T>& l = b.nodes[c]; KdNode<T>& r = b.nodes[c + 1];
-    kd_node_init(l, nd.left, nd.left + index);
-    kd_node_init(r, nd.left + index, nd.right);
-    for (int j = 0; j < 3; ++j) { l.bb_lo[j] = r.bb_lo[j] = nd.bb_lo[j]; l.bb_hi[j] = r.bb_hi[j] = nd.bb_hi[j]; }
-    l.bb_hi[nd.divfeat] = nd.cutval;
-    r.bb_lo[nd.divfeat] = nd.cutval;
-    nd.child1 = c; nd.child2 = c + 1; nd.active = 0;
-    l.depth = r.depth = nd.depth + 1;
-    atomicMax(b.max_depth, nd.depth + 1);
-    for (int k = 0; k < 2; ++k) {
-        const int id2 = c + k; const KdNode<T>& ch = k ? r : l;
-        if (ch.right - ch.left <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = id2;     // finished in LDS later
-        else b.next_nodes[atomicAdd(b.n_next, 1)] = id2;
+__global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b, int n_level) {
+    __shared__ int s_next, s_items;
+    if (threadIdx.x == 0) { s_next = 0; s_items = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_level; base += kBlock) {
+        const int i = base + threadIdx.x;
+        if (i < n_level) {
+            KdNode<T>& nd = b.nodes[b.level_nodes[i]];
+            const int count = nd.right - nd.left, lim1 = nd.lt, lim2 = nd.le;
+            int index;
+            if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
+            const int c = atomicAdd(b.n_nodes, 2);
+            KdNode<T>& l = b.nodes[c]; KdNode<T>& r = b.nodes[c + 1];
+            kd_node_init(l, nd.left, nd.left + index);
+            kd_node_init(r, nd.left + index, nd.right);
+            for (int j = 0; j < 3; ++j) { l.bb_lo[j] = r.bb_lo[j] = nd.bb_lo[j]; l.bb_hi[j] = r.bb_hi[j] = nd.bb_hi[j]; }
+            l.bb_hi[nd.divfeat] = nd.cutval;
+            r.bb_lo[nd.divfeat] = nd.cutval;
+            nd.child1 = c; nd.child2 = c + 1;
+            l.depth = r.depth = nd.depth + 1;
+            atomicMax(b.max_depth, nd.depth + 1);
+            for (int k = 0; k < 2; ++k) {
+                const int id2 = c + k; const int cnt = k ? count - index : index;
+                if (cnt <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = id2;     // finished in LDS later
+                else b.next_nodes[atomicAdd(&s_next, 1)] = id2;
+            }
+        }
     }
+    __syncthreads();
+    const int n_next = s_next;
+    for (int base = 0; base < n_next; base += kBlock) {      // chunk-prefix table of the next level
+        const int i = base + threadIdx.x;
+        unsigned nc = 0;
+        if (i < n_next) { const KdNode<T>& nd = b.nodes[b.next_nodes[i]]; nc = (unsigned)((nd.right - nd.left + kKdChunk - 1) / kKdChunk); }
+        unsigned total;
+        const unsigned ex = block_exclusive_scan(nc, &total);
+        if (i < n_next) b.next_cbase[i] = s_items + (int)ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_items += (int)total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { b.next_cbase[n_next] = s_items; *b.n_items = s_items; *b.n_next = n_next; }
 }
 
 // ---- sub-trees in LDS -------------------------------------------------------------------------------------------------
@@ -426,13 +415,22 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
         }
         if (tid == 0) s_misc[0] = 0;
         __syncthreads();
-        // S2: lim1, lim2
-        for (int p = tid; p < n; p += kSubThreads) {
-            const int i = seg[p];
-            if (i == 0xFFFF) continue;
-            const T v = reinterpret_cast<const T*>(E + p)[n_feat[i]];
-            if (v < n_cut[i]) atomicAdd(&n_lt[i], 1);
-            if (v <= n_cut[i]) atomicAdd(&n_le[i], 1);
+        // S2: lim1, lim2. Lanes hold consecutive positions, so a wave sees at most a few distinct nodes:
+        // one ballot-popcount + one LDS atomic per distinct node instead of two atomics per element.
+        for (int base = 0; base < n; base += kSubThreads) {
+            const int p = base + tid;
+            const int i = p < n ? seg[p] : 0xFFFF;
+            bool flt = false, fle = false;
+            if (i != 0xFFFF) { const T v = reinterpret_cast<const T*>(E + p)[n_feat[i]]; flt = v < n_cut[i]; fle = v <= n_cut[i]; }
+            unsigned long long rem = __ballot(i != 0xFFFF);
+            while (rem) {
+                const int leader = __ffsll((long long)rem) - 1;
+                const int key = __shfl(i, leader, 64);
+                const unsigned long long m = __ballot(i == key);
+                const unsigned long long mlt = __ballot(i == key && flt), mle = __ballot(i == key && fle);
+                if ((tid & 63) == leader) { atomicAdd(&n_lt[key], __popcll(mlt)); atomicAdd(&n_le[key], __popcll(mle)); }
+                rem &= ~m;
+            }
         }
         __syncthreads();
         // S3/S4 twice: ranked misplaced lists + pairwise swap (planeSplit loops 1 and 2)
@@ -526,17 +524,38 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
         }
         __syncthreads();
-        // S6: children's tight boxes + re-label elements
-        for (int p = tid; p < n; p += kSubThreads) {
-            const int i = seg[p];
-            if (i == 0xFFFF) continue;
-            const int k = p >= n_left[i] + n_idx[i];
-            const Pt4<T> v = E[p];
-            Enc* mm = c_mm + 6 * (2 * i + k);
-            atomicMin(&mm[0], enc(v.x)); atomicMax(&mm[3], enc(v.x));
-            atomicMin(&mm[1], enc(v.y)); atomicMax(&mm[4], enc(v.y));
-            atomicMin(&mm[2], enc(v.z)); atomicMax(&mm[5], enc(v.z));
-            seg[p] = child_slot[2 * i + k];
+        // S6: children's tight boxes + re-label elements. Up to two distinct children per wave are reduced with
+        // shuffles (one LDS atomic per value); lanes of further children fall back to per-element LDS atomics.
+        for (int base = 0; base < n; base += kSubThreads) {
+            const int p = base + tid;
+            const int i = p < n ? seg[p] : 0xFFFF;
+            int ck = -1; Pt4<T> v; v.x = v.y = v.z = 0; v.idx = 0;
+            if (i != 0xFFFF) { ck = 2 * i + (p >= n_left[i] + n_idx[i]); v = E[p]; }
+            unsigned long long rem = __ballot(ck >= 0);
+            for (int round = 0; round < 2 && rem; ++round) {
+                const int leader = __ffsll((long long)rem) - 1;
+                const int key = __shfl(ck, leader, 64);
+                const bool mine = ck == key;
+                const unsigned long long m = __ballot(mine);
+                const T lx = wave_min(mine ? v.x : Limits<T>::max_v), hx = wave_max(mine ? v.x : -Limits<T>::max_v);
+                const T ly = wave_min(mine ? v.y : Limits<T>::max_v), hy = wave_max(mine ? v.y : -Limits<T>::max_v);
+                const T lz = wave_min(mine ? v.z : Limits<T>::max_v), hz = wave_max(mine ? v.z : -Limits<T>::max_v);
+                if ((tid & 63) == leader) {
+                    Enc* mm = c_mm + 6 * key;
+                    atomicMin(&mm[0], enc(lx)); atomicMax(&mm[3], enc(hx));
+                    atomicMin(&mm[1], enc(ly)); atomicMax(&mm[4], enc(hy));
+                    atomicMin(&mm[2], enc(lz)); atomicMax(&mm[5], enc(hz));
+                }
+                if (mine) ck = -2 - ck;            // done (keep the key recoverable for the re-label below)
+                rem &= ~m;
+            }
+            if (ck >= 0) {
+                Enc* mm = c_mm + 6 * ck;
+                atomicMin(&mm[0], enc(v.x)); atomicMax(&mm[3], enc(v.x));
+                atomicMin(&mm[1], enc(v.y)); atomicMax(&mm[4], enc(v.y));
+                atomicMin(&mm[2], enc(v.z)); atomicMax(&mm[5], enc(v.z));
+            }
+            if (i != 0xFFFF) seg[p] = child_slot[ck >= 0 ? ck : -2 - ck];
         }
         __syncthreads();
         // S7: publish children's boxes; install the next level
@@ -567,7 +586,6 @@ struct KdSearchArgs {
     const Pt4<T>* qsorted; const int* qlist; const int* qcount_dev;
     int k, squared;
     T* out_d; long long* out_i;
-    T* scratch_d; int* scratch_i;       // k slots per work item (KNNResultSet storage)
     void* stack; int stack_cap;         // per work item: stack_cap frames (tree depth + 2) in global memory
     int* error_flag;
 };
@@ -575,83 +593,118 @@ struct KdSearchArgs {
 template <typename T>
 struct KdFrame { int node, other, idx, stage; T mindistsq, cut, dst; };
 
-// One lane per query: findNeighbors / computeInitialDistances / searchLevel / addPoint verbatim in behaviour
-// (nanoflann.hpp:1393-1418, :1164-1187, :1544-1624, :194-227), recursion unrolled onto an explicit stack.
+// One WAVE per tied query: findNeighbors / computeInitialDistances / searchLevel / addPoint verbatim in behaviour
+// (nanoflann.hpp:1393-1418, :1164-1187, :1544-1624, :194-227). The control flow is wave-uniform (every lane runs the
+// same scalar recursion, unrolled onto an explicit stack); at a leaf the lanes fetch the leaf's points together and
+// evaluate their distances in parallel, then the points are offered to the result set one by one in vAcc order,
+// exactly as the reference's loop does.
 template <typename T>
 __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= *a.qcount_dev) return;
     const Pt4<T> q = a.qsorted[a.qlist[t]];
     const T vec[3] = {q.x, q.y, q.z};
     const int k = a.k;
-    T* rd = a.scratch_d + (size_t)t * k; int* ri = a.scratch_i + (size_t)t * k;
+    __shared__ T rd[128]; __shared__ int ri[128];                       // KNNResultSet storage (k <= 128)
+    __shared__ T s_dists[3]; __shared__ T s_vec[3];                     // indexed by the split dimension: kept in LDS so
+                                                                        // that no select chain on a uniform index is generated
     int count = 0;
-    rd[k - 1] = Limits<T>::max_v;                                       // KNNResultSet::init (:176-183)
+    if (lane == 0) rd[k - 1] = Limits<T>::max_v;                        // KNNResultSet::init (:176-183)
+    __syncthreads();
     const KdNode<T>& root = a.nodes[0];
     T dists[3] = {0, 0, 0};
     T distsq = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {                                       // computeInitialDistances on root_bbox
         const T lo = dec(root.mm_lo[i]), hi = dec(root.mm_hi[i]);
         if (vec[i] < lo) { dists[i] = (vec[i] - lo) * (vec[i] - lo); distsq += dists[i]; }
         if (vec[i] > hi) { dists[i] = (vec[i] - hi) * (vec[i] - hi); distsq += dists[i]; }
     }
+    if (lane < 3) { s_dists[lane] = lane == 0 ? dists[0] : (lane == 1 ? dists[1] : dists[2]); s_vec[lane] = lane == 0 ? q.x : (lane == 1 ? q.y : q.z); }
+    __syncthreads();
     typedef KdFrame<T> Frame;
     Frame* st = reinterpret_cast<Frame*>(a.stack) + (size_t)t * a.stack_cap;     // recursion depth <= tree depth
     int sp = 0;
-    st[0].node = 0; st[0].stage = 0; st[0].mindistsq = distsq;
-    while (sp >= 0) {
-        Frame& f = st[sp];
+    Frame f; f.node = 0; f.stage = 0; f.mindistsq = distsq; f.other = 0; f.idx = 0; f.cut = 0; f.dst = 0;
+    // `f` is the frame on top (kept in registers, wave-uniform); st[] holds the frames below it.
+    while (true) {
         const KdNode<T>& nd = a.nodes[f.node];
+        bool pop = false;
         if (f.stage == 0) {
             if (nd.child1 < 0) {                                        // leaf (:1552-1572)
-                const T worst_dist = rd[k - 1];
-                for (int i = nd.left; i < nd.right; ++i) {
-                    const Pt4<T> c = a.E[i];
-                    T d = 0;
-                    { const T diff = vec[0] - c.x; d += diff * diff; }
-                    { const T diff = vec[1] - c.y; d += diff * diff; }
-                    { const T diff = vec[2] - c.z; d += diff * diff; }
-                    if (d < worst_dist) {                               // addPoint (:194-227)
-                        int j;
-                        for (j = count; j > 0; --j) {
-                            if (rd[j - 1] > d) { if (j < k) { rd[j] = rd[j - 1]; ri[j] = ri[j - 1]; } }
-                            else break;
-                        }
-                        if (j < k) { rd[j] = d; ri[j] = (int)c.idx; }
-                        if (count < k) count++;
+                const T worst_dist = rd[k - 1];                         // sampled once per leaf
+                for (int base = nd.left; base < nd.right; base += 64) {
+                    const int cnt = min(64, nd.right - base);
+                    T d = 0; int id = 0;
+                    if (lane < cnt) {
+                        const Pt4<T> c = a.E[base + lane];
+                        { const T diff = vec[0] - c.x; d += diff * diff; }
+                        { const T diff = vec[1] - c.y; d += diff * diff; }
+                        { const T diff = vec[2] - c.z; d += diff * diff; }
+                        id = (int)c.idx;
                     }
+                    for (int e = 0; e < cnt; ++e) {
+                        const T de = __shfl(d, e, 64); const int ie = __shfl(id, e, 64);
+                        if (de < worst_dist) {                          // addPoint (:194-227), lane 0 owns the arrays
+                            if (lane == 0) {
+                                int j;
+                                for (j = count; j > 0; --j) {
+                                    if (rd[j - 1] > de) { if (j < k) { rd[j] = rd[j - 1]; ri[j] = ri[j - 1]; } }
+                                    else break;
+                                }
+                                if (j < k) { rd[j] = de; ri[j] = ie; }
+                            }
+                            if (count < k) count++;
+                        }
+                    }
+                    __syncthreads();
                 }
-                --sp;
-                continue;
+                pop = true;
+            } else {
+                const int idx = nd.divfeat;
+                const T val = s_vec[idx];
+                const T divlow = dec(a.nodes[nd.child1].mm_hi[idx]);    // left_bbox[cutfeat].high after recursion (:1048)
+                const T divhigh = dec(a.nodes[nd.child2].mm_lo[idx]);   // right_bbox[cutfeat].low (:1049)
+                const T diff1 = val - divlow, diff2 = val - divhigh;
+                int best;
+                if ((diff1 + diff2) < 0) { best = nd.child1; f.other = nd.child2; f.cut = (val - divhigh) * (val - divhigh); }
+                else { best = nd.child2; f.other = nd.child1; f.cut = (val - divlow) * (val - divlow); }
+                f.idx = idx; f.stage = 1;
+                if (sp + 1 >= a.stack_cap) { if (lane == 0) *a.error_flag = 1; return; }
+                if (lane == 0) st[sp] = f;
+                ++sp;
+                const T m = f.mindistsq;
+                f.node = best; f.stage = 0; f.mindistsq = m;
             }
-            const int idx = nd.divfeat;
-            const T val = vec[idx];
-            const T divlow = dec(a.nodes[nd.child1].mm_hi[idx]);        // left_bbox[cutfeat].high after recursion (:1048)
-            const T divhigh = dec(a.nodes[nd.child2].mm_lo[idx]);       // right_bbox[cutfeat].low (:1049)
-            const T diff1 = val - divlow, diff2 = val - divhigh;
-            int best;
-            if ((diff1 + diff2) < 0) { best = nd.child1; f.other = nd.child2; f.cut = (val - divhigh) * (val - divhigh); }
-            else { best = nd.child2; f.other = nd.child1; f.cut = (val - divlow) * (val - divlow); }
-            f.idx = idx; f.stage = 1;
-            if (sp + 1 >= a.stack_cap) { *a.error_flag = 1; return; }
-            ++sp; st[sp].node = best; st[sp].stage = 0; st[sp].mindistsq = f.mindistsq;
         } else if (f.stage == 1) {
-            f.dst = dists[f.idx];
+            f.dst = s_dists[f.idx];
             const T m2 = f.mindistsq + f.cut - f.dst;
-            dists[f.idx] = f.cut;
+            __syncthreads();
+            if (lane == 0) s_dists[f.idx] = f.cut;
+            __syncthreads();
             f.stage = 2;
             if (m2 * 1.0f <= rd[k - 1]) {
-                if (sp + 1 >= a.stack_cap) { *a.error_flag = 1; return; }
-                const int other = f.other;
-                ++sp; st[sp].node = other; st[sp].stage = 0; st[sp].mindistsq = m2;
+                if (sp + 1 >= a.stack_cap) { if (lane == 0) *a.error_flag = 1; return; }
+                if (lane == 0) st[sp] = f;
+                ++sp;
+                f.node = f.other; f.stage = 0; f.mindistsq = m2;
             }
         } else {
-            dists[f.idx] = f.dst;
+            __syncthreads();
+            if (lane == 0) s_dists[f.idx] = f.dst;
+            __syncthreads();
+            pop = true;
+        }
+        if (pop) {
+            if (sp == 0) break;
             --sp;
+            __syncthreads();
+            f = st[sp];                                                  // written by lane 0 of this wave
         }
     }
+    __syncthreads();
     const size_t o = (size_t)q.idx * (size_t)k;
-    for (int j = 0; j < k; ++j) {                                       // src/point_cloud_distance.cpp:82-93
+    for (int j = lane; j < k; j += 64) {                                // src/point_cloud_distance.cpp:82-93
         if (j < count) { a.out_i[o + j] = ri[j]; a.out_d[o + j] = a.squared ? rd[j] : sqrt(rd[j]); }
         else { a.out_i[o + j] = -1; a.out_d[o + j] = (T)-1; }
     }

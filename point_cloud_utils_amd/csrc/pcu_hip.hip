@@ -144,10 +144,12 @@ static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t 
 
 // ------------------------------------------------------------------------------------------------ search driver
 static double default_occupancy(int k) {
-    // points per cell so that the k-th neighbour lies within one cell edge of the query with high probability
-    // for locally uniform data: the ball of radius 1.12 h holds ~5.9*occ points.
-    if (k <= 1) return 1.5;
-    return std::max(2.0, (k + 3.0 * sqrt((double)k)) / 5.9);
+    // Dataset points per grid cell. More points per cell = more candidates per query in the main pass but fewer
+    // queries whose k-th neighbour lies beyond the certified radius (one cell edge) and must be re-run by the
+    // wave-per-query passes. Measured optimum on uniform data (profiles/r01_occupancy_sweep.txt): 2.0 for k = 1,
+    // 7-8 for k = 16; in between the k-th neighbour radius scales with (k + 3 sqrt k)^(1/3).
+    if (k <= 1) return 2.0;
+    return std::max(2.0, (k + 3.0 * sqrt((double)k)) / 3.7);
 }
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 constexpr int kMaxK = 64;           // lane-per-query slots; the wave kernel uses up to 128 (k+1 rounded up)
@@ -256,7 +258,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     int* counters = nullptr;
     if (aalloc(ar, &b.E, (size_t)M) || aalloc(ar, &b.nodes, max_nodes) || aalloc(ar, &counters, 16)) return -1;
     if (aalloc(ar, &b.level_nodes, max_level) || aalloc(ar, &b.next_nodes, max_level)) return -1;
-    if (aalloc(ar, &b.item_node, max_items) || aalloc(ar, &b.item_chunk, max_items)) return -1;
+    if (aalloc(ar, &b.level_cbase, max_level + 1) || aalloc(ar, &b.next_cbase, max_level + 1)) return -1;
     if (aalloc(ar, &b.chunk_bl, max_items) || aalloc(ar, &b.chunk_br, max_items)) return -1;
     if (aalloc(ar, &b.BLpos, (size_t)M) || aalloc(ar, &b.BRpos, (size_t)M)) return -1;
     if (aalloc(ar, &b.sub_nodes, max_level)) return -1;
@@ -273,25 +275,22 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     for (int level = 0; n_level > 0; ++level) {
         if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
         const int items_ub = M / kKdChunk + n_level + 1;
-        const int nlb = (n_level + kBlock - 1) / kBlock;
 #define KD_STEP(name, ...) do { __VA_ARGS__; if (dbg) { hipError_t e_ = hipStreamSynchronize(s); fprintf(stderr, "[kd] level %d n=%d %s -> %s\n", level, n_level, name, hipGetErrorString(e_)); } } while (0)
-        KD_STEP("plan", hipLaunchKernelGGL(k_kd_plan<T>, dim3(1), dim3(kBlock), 0, s, b, n_level));
-        KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
-        KD_STEP("choose", hipLaunchKernelGGL(k_kd_choose<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level));
-        KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
+        KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level));
+        KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level));
         for (int ph = 0; ph < 2; ++ph) {
-            KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-            KD_STEP("chunk_scan", hipLaunchKernelGGL(k_kd_chunk_scan<T>, dim3(n_level), dim3(kBlock), 0, s, b, n_level, ph));
-            KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-            KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+            KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
+            KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
+            KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
         }
-        KD_STEP("split", hipLaunchKernelGGL(k_kd_split<T>, dim3(nlb), dim3(kBlock), 0, s, b, n_level));
+        KD_STEP("advance", hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, b, n_level));
 #undef KD_STEP
         HIP_TRY(hipGetLastError());
         int n_next = 0;
         HIP_TRY(hipMemcpyAsync(&n_next, b.n_next, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         std::swap(b.level_nodes, b.next_nodes);
+        std::swap(b.level_cbase, b.next_cbase);
         n_level = n_next;
         level_count = level + 1;
     }
@@ -326,12 +325,11 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     KdSearchArgs<T> a;
     a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
     a.k = j.k; a.squared = j.squared ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
-    if (aalloc(ar, &a.scratch_d, (size_t)n_tt * j.k) || aalloc(ar, &a.scratch_i, (size_t)n_tt * j.k)) return -1;
     KdFrame<T>* frames = nullptr;
     a.stack_cap = levels + 2;
     if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
     a.stack = frames;
-    hipLaunchKernelGGL(k_kd_search<T>, dim3((n_tt + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
     HIP_TRY(hipGetLastError());
     if (st) (void)hipEventRecord(e1, s);
     int herr = 0;
