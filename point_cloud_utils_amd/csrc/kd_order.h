@@ -47,7 +47,9 @@ template <typename T>
 struct KdBuild {
     Pt4<T>* E;                           // permuted elements
     KdNode<T>* nodes;
-    int* n_nodes;                        // device counter
+    int* n_nodes;                        // node-id allocator (upper bound of ids in use)
+    int* n_real;                         // number of nodes actually created (diagnostics)
+    int* n_cur;                          // number of nodes in level_nodes (device-resident: no host sync per level)
     int* level_nodes;                    // node ids of the current level
     int* next_nodes; int* n_next;        // node ids created for the next level
     int* level_cbase; int* next_cbase;   // exclusive prefix of chunk counts over the level's nodes (+ total)
@@ -90,17 +92,17 @@ __global__ void k_kd_root(KdBuild<T> b, const GridParams<T>* gp, int n) {
     KdNode<T>& nd = b.nodes[0];
     kd_node_init(nd, 0, n);
     for (int j = 0; j < 3; ++j) { nd.bb_lo[j] = gp->gmin[j]; nd.bb_hi[j] = gp->gmax[j]; }
-    *b.n_nodes = 1; *b.n_next = 0; *b.n_sub = 0; *b.max_depth = 0;
-    if (n <= b.sub_max) { b.sub_nodes[0] = 0; *b.n_sub = 1; *b.n_items = 0; b.level_nodes[0] = -1; }
-    else { b.level_nodes[0] = 0; b.level_cbase[0] = 0; b.level_cbase[1] = (n + kKdChunk - 1) / kKdChunk; *b.n_items = b.level_cbase[1]; }
+    *b.n_nodes = 1; *b.n_real = 1; *b.n_next = 0; *b.n_sub = 0; *b.max_depth = 0;
+    if (n <= b.sub_max) { b.sub_nodes[0] = 0; *b.n_sub = 1; *b.n_items = 0; *b.n_cur = 0; }
+    else { *b.n_cur = 1; b.level_nodes[0] = 0; b.level_cbase[0] = 0; b.level_cbase[1] = (n + kKdChunk - 1) / kKdChunk; *b.n_items = b.level_cbase[1]; }
 }
 
 // ---- per level (nodes too large for one workgroup): 9 launches -------------------------------------------------
 // Work items are (node, chunk) pairs; a block finds its pair by a binary search in the level's chunk-prefix table.
 template <typename T>
-__device__ __forceinline__ bool kd_locate(const KdBuild<T>& b, int n_level, int wi, int& node_id, int& chunk) {
+__device__ __forceinline__ bool kd_locate(const KdBuild<T>& b, int wi, int& node_id, int& chunk) {
     if (wi >= *b.n_items) return false;
-    int lo = 0, hi = n_level;                         // level_cbase[lo] <= wi < level_cbase[hi]
+    int lo = 0, hi = *b.n_cur;                         // level_cbase[lo] <= wi < level_cbase[hi]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.level_cbase[mid] <= wi) lo = mid; else hi = mid; }
     node_id = b.level_nodes[lo]; chunk = wi - b.level_cbase[lo];
     return true;
@@ -108,9 +110,9 @@ __device__ __forceinline__ bool kd_locate(const KdBuild<T>& b, int n_level, int 
 
 // K1: tight min/max (computeMinMax) of every node of the level
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b, int n_level) {
+__global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b) {
     int id, chunk;
-    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
@@ -160,9 +162,9 @@ __device__ __forceinline__ void kd_choose(const T* bb_lo, const T* bb_hi, const 
 // K2: every block re-derives its node's cut (cheap scalar work, saves a launch), chunk 0 records it;
 //     lim1 - left = #(< cutval), lim2 - left = #(<= cutval)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b, int n_level) {
+__global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b) {
     int id, chunk;
-    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     T mn[3], mx[3];
     for (int j = 0; j < 3; ++j) { mn[j] = dec(nd.mm_lo[j]); mx[j] = dec(nd.mm_hi[j]); }
@@ -190,9 +192,9 @@ __device__ __forceinline__ void kd_flags(const KdNode<T>& nd, int ph, int p, T v
 // K3: per work item counts of misplaced-left / misplaced-right. Loop 2 has nothing to do when no element equals
 // the cut value (lt == le): its three launches then exit at once.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int n_level, int ph) {
+__global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
     int id, chunk;
-    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     const int wi = blockIdx.x;
     if (ph == 1 && nd.lt == nd.le) { if (threadIdx.x == 0) { b.chunk_bl[wi] = 0; b.chunk_br[wi] = 0; } return; }
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int n_lev
 // ranks count from the node's left end, misplaced-right ranks from its right end). Thread t owns kKdItems
 // consecutive positions so ranks follow position order.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int n_level, int ph) {
+__global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
     int id, chunk;
-    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     if (ph == 1 && nd.lt == nd.le) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[1] = 0; return; }
     const int wi = blockIdx.x, wi0 = wi - chunk, nc = (nd.right - nd.left + kKdChunk - 1) / kKdChunk;
@@ -251,9 +253,9 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int n_level, 
 
 // K5: swap the j-th misplaced-left with the j-th misplaced-right (std::swap in planeSplit, :1137 / :1155)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int n_level, int ph) {
+__global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int ph) {
     int id, chunk;
-    if (!kd_locate(b, n_level, blockIdx.x, id, chunk)) return;
+    if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     const int j0 = chunk * kKdChunk, nb = nd.nbad[ph];
     for (int j = j0 + threadIdx.x; j < min(j0 + kKdChunk, nb); j += kBlock) {
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int n_level, i
 // K6 (one block): split index (middleSplit_ tail, :1104-1109), the two children with their hand-down boxes
 // (:1040-1046), routing of each child (next level / LDS sub-tree list), and the next level's chunk-prefix table.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b, int n_level) {
+__global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
+    const int n_level = *b.n_cur;
     __shared__ int s_next, s_items;
     if (threadIdx.x == 0) { s_next = 0; s_items = 0; }
     __syncthreads();
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b, int n_level
             int index;
             if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
             const int c = atomicAdd(b.n_nodes, 2);
+            atomicAdd(b.n_real, 2);
             KdNode<T>& l = b.nodes[c]; KdNode<T>& r = b.nodes[c + 1];
             kd_node_init(l, nd.left, nd.left + index);
             kd_node_init(r, nd.left + index, nd.right);
@@ -324,7 +328,7 @@ template <typename T>
 __host__ __device__ constexpr size_t kd_sub_lds_bytes() {
     typedef typename EncT<T>::type Enc;
     return (size_t)KdSub<T>::S * sizeof(Pt4<T>) + 3 * (size_t)KdSub<T>::S * 2 + 13 * (size_t)KdSub<T>::CAP * 4 + (size_t)KdSub<T>::CAP * sizeof(T) +
-           18 * (size_t)KdSub<T>::CAP * sizeof(Enc) + 2 * (size_t)KdSub<T>::CAP * 2 + 256;
+           18 * (size_t)KdSub<T>::CAP * sizeof(Enc) + 2 * (size_t)KdSub<T>::CAP * 2 + 6 * (size_t)KdSub<T>::CAP * sizeof(T) + 256;
 }
 
 __device__ __forceinline__ void block_scan2_512(unsigned a, unsigned b2, unsigned& ea, unsigned& eb, unsigned& ta, unsigned& tb, unsigned* s_w /*34 words*/) {
@@ -361,7 +365,8 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     Enc* c_mm = cur_mm + 6 * CAP;                                              // [2*CAP][6]
     unsigned short* child_slot = reinterpret_cast<unsigned short*>(c_mm + 12 * CAP);   // [2*CAP]
     unsigned* s_w = reinterpret_cast<unsigned*>(child_slot + 2 * CAP);        // 34 words scan scratch + misc
-    int* s_misc = reinterpret_cast<int*>(s_w + 40);                            // [0]=n_next [1]=id base
+    int* s_misc = reinterpret_cast<int*>(s_w + 40);                            // [0]=n_next [1]=id base [2]=loop-2 needed [3]=nodes created
+    T* n_bb = reinterpret_cast<T*>(s_misc + 8);                                // [CAP][6] hand-down boxes of the active nodes
 
     const int root_gid = b.sub_nodes[blockIdx.x];
     KdNode<T>& root = b.nodes[root_gid];
@@ -370,8 +375,15 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     for (int p = tid; p < n; p += kSubThreads) { E[p] = b.E[g0 + p]; seg[p] = 0; }
     for (int p = n + tid; p < S; p += kSubThreads) seg[p] = 0xFFFF;
     if (tid < 6) cur_mm[tid] = tid < 3 ? ~(Enc)0 : (Enc)0;
-    if (tid == 0) { n_gid[0] = root_gid; n_left[0] = 0; n_right[0] = n; }
+    if (tid == 0) {
+        n_gid[0] = root_gid; n_left[0] = 0; n_right[0] = n;
+        for (int j = 0; j < 3; ++j) { n_bb[j] = root.bb_lo[j]; n_bb[3 + j] = root.bb_hi[j]; }
+        // ids for the whole sub-tree (at most 2n-2 nodes below the sub-root) are reserved with ONE global atomic
+        s_misc[1] = n > b.leaf_max ? atomicAdd(b.n_nodes, 2 * n) : 0; s_misc[3] = 0;
+    }
     __syncthreads();
+    const int root_depth = root.depth;
+    int sub_level = 0;
     {   // tight box of the sub-root (computeMinMax); wave pre-reduction, then LDS atomics
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
         for (int p = tid; p < n; p += kSubThreads) {
@@ -394,26 +406,15 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     while (n_act > 0) {
         // S1: leaf test is implied (only nodes with count > leaf_max are active); middleSplit_ head
         if (tid < n_act) {
+            int cutfeat; T cutval;
+            T mn[3], mx[3];
+            for (int d = 0; d < 3; ++d) { mn[d] = dec(cur_mm[6 * tid + d]); mx[d] = dec(cur_mm[6 * tid + 3 + d]); }
+            kd_choose(n_bb + 6 * tid, n_bb + 6 * tid + 3, mn, mx, cutfeat, cutval);
             KdNode<T>& nd = b.nodes[n_gid[tid]];
-            const T EPS = (T)0.00001;
-            T max_span = nd.bb_hi[0] - nd.bb_lo[0];
-            for (int d = 1; d < 3; ++d) { const T span = nd.bb_hi[d] - nd.bb_lo[d]; if (span > max_span) max_span = span; }
-            T max_spread = -1; int cutfeat = 0;
-            for (int d = 0; d < 3; ++d) {
-                const T span = nd.bb_hi[d] - nd.bb_lo[d];
-                if (span > ((T)1 - EPS) * max_span) {
-                    const T spread = dec(cur_mm[6 * tid + 3 + d]) - dec(cur_mm[6 * tid + d]);
-                    if (spread > max_spread) { cutfeat = d; max_spread = spread; }
-                }
-            }
-            const T split_val = (nd.bb_lo[cutfeat] + nd.bb_hi[cutfeat]) / (T)2;
-            const T mn = dec(cur_mm[6 * tid + cutfeat]), mx = dec(cur_mm[6 * tid + 3 + cutfeat]);
-            T cutval;
-            if (split_val < mn) cutval = mn; else if (split_val > mx) cutval = mx; else cutval = split_val;
             nd.divfeat = cutfeat; nd.cutval = cutval;
             n_feat[tid] = cutfeat; n_cut[tid] = cutval; n_lt[tid] = 0; n_le[tid] = 0;
         }
-        if (tid == 0) s_misc[0] = 0;
+        if (tid == 0) { s_misc[2] = 0; s_misc[0] = 0; }
         __syncthreads();
         // S2: lim1, lim2. Lanes hold consecutive positions, so a wave sees at most a few distinct nodes:
         // one ballot-popcount + one LDS atomic per distinct node instead of two atomics per element.
@@ -433,8 +434,11 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
         }
         __syncthreads();
-        // S3/S4 twice: ranked misplaced lists + pairwise swap (planeSplit loops 1 and 2)
-        for (int ph = 0; ph < 2; ++ph) {
+        if (tid < n_act && n_lt[tid] != n_le[tid]) s_misc[2] = 1;      // some element equals its node's cut value
+        __syncthreads();
+        const int n_ph = s_misc[2] ? 2 : 1;                             // planeSplit's second loop has nothing to move otherwise
+        // S3/S4: ranked misplaced lists + pairwise swap (planeSplit loops 1 and 2)
+        for (int ph = 0; ph < n_ph; ++ph) {
             bool bl[IPT], br[IPT];
             unsigned nl = 0, nr = 0;
 #pragma unroll
@@ -494,9 +498,8 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
             __syncthreads();
         }
-        // S5: split index, children
-        if (tid == 0) s_misc[1] = atomicAdd(b.n_nodes, 2 * n_act);
-        __syncthreads();
+        // S5: split index, children (ids come from the block's reserved range: no global round trip)
+        T cbb[12];                                   // hand-down boxes of this thread's two children, installed in S7
         if (tid < n_act) {
             const int gid = n_gid[tid];
             KdNode<T>& nd = b.nodes[gid];
@@ -504,15 +507,16 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             int index;
             if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
             n_idx[tid] = index;
-            const int c = s_misc[1] + 2 * tid;
+            const int c = s_misc[1] + s_misc[3] + 2 * tid;
             KdNode<T>& l = b.nodes[c]; KdNode<T>& r = b.nodes[c + 1];
             kd_node_init(l, g0 + n_left[tid], g0 + n_left[tid] + index);
             kd_node_init(r, g0 + n_left[tid] + index, g0 + n_right[tid]);
-            for (int j = 0; j < 3; ++j) { l.bb_lo[j] = r.bb_lo[j] = nd.bb_lo[j]; l.bb_hi[j] = r.bb_hi[j] = nd.bb_hi[j]; }
-            l.bb_hi[nd.divfeat] = nd.cutval; r.bb_lo[nd.divfeat] = nd.cutval;
-            l.depth = r.depth = nd.depth + 1;
+            const int f = n_feat[tid]; const T cut = n_cut[tid];
+            for (int j = 0; j < 6; ++j) { cbb[j] = n_bb[6 * tid + j]; cbb[6 + j] = n_bb[6 * tid + j]; }
+            for (int j = 0; j < 3; ++j) if (j == f) { cbb[3 + j] = cut; cbb[6 + j] = cut; }
+            for (int j = 0; j < 3; ++j) { l.bb_lo[j] = cbb[j]; l.bb_hi[j] = cbb[3 + j]; r.bb_lo[j] = cbb[6 + j]; r.bb_hi[j] = cbb[9 + j]; }
+            l.depth = r.depth = root_depth + sub_level + 1;
             nd.child1 = c; nd.child2 = c + 1;
-            atomicMax(b.max_depth, nd.depth + 1);
             for (int k = 0; k < 2; ++k) {
                 const int cl = k ? n_left[tid] + index : n_left[tid], cr = k ? n_right[tid] : n_left[tid] + index;
                 for (int j = 0; j < 3; ++j) { c_mm[6 * (2 * tid + k) + j] = ~(Enc)0; c_mm[6 * (2 * tid + k) + 3 + j] = 0; }
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
         // S7: publish children's boxes; install the next level
         const int n_next = s_misc[0];
         for (int cidx = tid; cidx < 2 * n_act; cidx += kSubThreads) {
-            KdNode<T>& ch = b.nodes[s_misc[1] + cidx];
+            KdNode<T>& ch = b.nodes[s_misc[1] + s_misc[3] + cidx];
             for (int j = 0; j < 3; ++j) { ch.mm_lo[j] = c_mm[6 * cidx + j]; ch.mm_hi[j] = c_mm[6 * cidx + 3 + j]; }
         }
         __syncthreads();
@@ -573,10 +577,15 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
         if (tid < n_next) { xg = x_gid[tid]; xl = x_left[tid]; xr = x_right[tid]; }
         __syncthreads();
         if (tid < n_next) { n_gid[tid] = xg; n_left[tid] = xl; n_right[tid] = xr; }
-        n_act = n_next;
+        if (tid < n_act) {
+            for (int k = 0; k < 2; ++k) { const int slot = child_slot[2 * tid + k]; if (slot != 0xFFFF) for (int j = 0; j < 6; ++j) n_bb[6 * slot + j] = cbb[6 * k + j]; }
+        }
+        if (tid == 0) { s_misc[3] += 2 * n_act; atomicMax(b.max_depth, root_depth + sub_level + 1); }
+        n_act = n_next; ++sub_level;
         __syncthreads();
     }
     for (int p = tid; p < n; p += kSubThreads) b.E[g0 + p] = E[p];
+    if (tid == 0 && s_misc[3]) atomicAdd(b.n_real, s_misc[3]);
 }
 
 // ---- nanoflann search for the tied queries ---------------------------------------------------------------------------

@@ -253,51 +253,62 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 // traversal (kd_order.h). Only called when the grid search reported genuine ties.
 template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
-                           KdBuild<T>& b, int** err_out, int* levels_out) {
-    const size_t max_nodes = 2 * (size_t)M + 2, max_level = (size_t)M + 2, max_items = (size_t)M / kKdChunk + max_level + 2;
+                           KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out) {
+    b.leaf_max = leaf_max;
+    b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
+    // level lists only ever hold nodes with more than sub_max elements
+    const size_t max_level = (size_t)M / (size_t)(b.sub_max + 1) + 4;
+    // node ids: < 2*max_level for the top levels, plus 2n reserved by each LDS sub-tree block (sum of n <= M)
+    const size_t max_nodes = 2 * (size_t)M + 4 * max_level + 16;
+    const size_t max_items = (size_t)M / kKdChunk + max_level + 2;
     int* counters = nullptr;
     if (aalloc(ar, &b.E, (size_t)M) || aalloc(ar, &b.nodes, max_nodes) || aalloc(ar, &counters, 16)) return -1;
     if (aalloc(ar, &b.level_nodes, max_level) || aalloc(ar, &b.next_nodes, max_level)) return -1;
     if (aalloc(ar, &b.level_cbase, max_level + 1) || aalloc(ar, &b.next_cbase, max_level + 1)) return -1;
     if (aalloc(ar, &b.chunk_bl, max_items) || aalloc(ar, &b.chunk_br, max_items)) return -1;
     if (aalloc(ar, &b.BLpos, (size_t)M) || aalloc(ar, &b.BRpos, (size_t)M)) return -1;
-    if (aalloc(ar, &b.sub_nodes, max_level)) return -1;
-    b.n_nodes = counters; b.n_next = counters + 1; b.n_items = counters + 2;
+    if (aalloc(ar, &b.sub_nodes, 2 * max_level + (size_t)M / (size_t)(b.sub_max / 2 + 1) + 16)) return -1;
+    b.n_nodes = counters; b.n_items = counters + 2;
     *err_out = counters + 3;
-    b.n_sub = counters + 4; b.max_depth = counters + 5;
-    b.leaf_max = leaf_max;
-    b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
+    b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
+    b.n_cur = counters + 7; b.n_next = counters + 8;
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
-    int n_level = M > b.sub_max ? 1 : 0, level_count = 0;
     const bool dbg = getenv("PCU_HIP_DEBUG_KD") != nullptr;
-    for (int level = 0; n_level > 0; ++level) {
-        if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
-        const int items_ub = M / kKdChunk + n_level + 1;
-#define KD_STEP(name, ...) do { __VA_ARGS__; if (dbg) { hipError_t e_ = hipStreamSynchronize(s); fprintf(stderr, "[kd] level %d n=%d %s -> %s\n", level, n_level, name, hipGetErrorString(e_)); } } while (0)
-        KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level));
-        KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level));
-        for (int ph = 0; ph < 2; ++ph) {
-            KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
-            KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
-            KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, n_level, ph));
-        }
-        KD_STEP("advance", hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, b, n_level));
+    const int items_ub = (int)max_items;
+    // The number of nodes per level lives on the device; kernels of an exhausted level exit at once. Levels are
+    // therefore enqueued in batches without any host round trip: first the expected log2(M / sub_max) + 2, then 4
+    // at a time until the device reports an empty level.
+    int expected = 2;
+    for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
+    int hcnt[16];
+    int level = 0;
+    for (int batch = M > b.sub_max ? expected : 0; batch > 0; batch = 4) {
+        for (int i = 0; i < batch; ++i, ++level) {
+#define KD_STEP(name, ...) do { __VA_ARGS__; if (dbg) { hipError_t e_ = hipStreamSynchronize(s); fprintf(stderr, "[kd] level %d %s -> %s\n", level, name, hipGetErrorString(e_)); } } while (0)
+            KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
+            KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
+            for (int ph = 0; ph < 2; ++ph) {
+                KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+                KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+                KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
+            }
+            KD_STEP("advance", hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, b));
 #undef KD_STEP
+            std::swap(b.level_nodes, b.next_nodes);
+            std::swap(b.level_cbase, b.next_cbase);
+            std::swap(b.n_cur, b.n_next);
+        }
         HIP_TRY(hipGetLastError());
-        int n_next = 0;
-        HIP_TRY(hipMemcpyAsync(&n_next, b.n_next, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        std::swap(b.level_nodes, b.next_nodes);
-        std::swap(b.level_cbase, b.next_cbase);
-        n_level = n_next;
-        level_count = level + 1;
+        if (hcnt[b.n_cur - counters] == 0) break;
+        if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
     }
-    (void)c; (void)level_count;
+    (void)c;
     // finish every small node inside one workgroup's LDS
-    int hcnt[8];
-    HIP_TRY(hipMemcpyAsync(hcnt, b.n_nodes, sizeof hcnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int n_sub = hcnt[4];
     if (n_sub > 0) {
@@ -310,9 +321,10 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         hipLaunchKernelGGL(k_kd_subtree<T>, dim3(n_sub), dim3(kSubThreads), kd_sub_lds_bytes<T>(), s, b);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(hcnt, b.n_nodes, sizeof hcnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *levels_out = hcnt[5] + 1;      // tree depth (root = 0) + 1
+    if (n_real_out) *n_real_out = hcnt[6];
     return 0;
 }
 
@@ -321,7 +333,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     KdBuild<T> b; int* err = nullptr; int levels = 0;
     hipEvent_t e0 = c->ev[4], e1 = c->ev[5];
     if (st) (void)hipEventRecord(e0, s);
-    if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels)) return -1;
+    if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr)) return -1;
     KdSearchArgs<T> a;
     a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
     a.k = j.k; a.squared = j.squared ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
@@ -669,12 +681,10 @@ static int debug_kd(pcu_hip_ctx* c, const T* pts, int64_t n, int leaf_max, int64
         GridIndex<T> gi;
         if ((rc = index_alloc(ar, gi, n, 2.0))) break;
         if ((rc = index_build(gi, dp, 2.0, s))) break;
-        KdBuild<T> b; int* err = nullptr; int levels = 0;
-        if ((rc = kd_build_device(c, ar, s, dp, (int)n, gi.gp, leaf_max > 0 ? leaf_max : 10, b, &err, &levels))) break;
+        KdBuild<T> b; int* err = nullptr; int levels = 0, nn = 0;
+        if ((rc = kd_build_device(c, ar, s, dp, (int)n, gi.gp, leaf_max > 0 ? leaf_max : 10, b, &err, &levels, &nn))) break;
         std::vector<Pt4<T>> h((size_t)n);
-        int nn = 0;
         HIP_TRY(hipMemcpy(h.data(), b.E, (size_t)n * sizeof(Pt4<T>), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&nn, b.n_nodes, sizeof(int), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < n; ++i) out_vacc[i] = (int64_t)h[(size_t)i].idx;
         *out_nnodes = nn;
     } while (0);
