@@ -60,6 +60,7 @@ struct KdBuild {
     int* max_depth;
     int leaf_max;
     int sub_max;                         // nodes with <= sub_max elements go to sub_nodes
+    long long* prof;                     // nullable: per-stage cycle counters of sub-tree block 0 (diagnostics)
 };
 
 // Coordinate d of element p, read straight from memory at a computed offset. (A `d == 0 ? x : d == 1 ? y : z`
@@ -320,8 +321,10 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
 // __syncthreads() in place of kernel boundaries, then writes the permuted elements back. This removes the many
 // launches over ever smaller nodes that dominate a purely level-synchronous build (the last ~15 of ~25 levels).
 template <typename T> struct KdSub;
-template <> struct KdSub<float>  { static constexpr int S = 4096, CAP = 384; };
-template <> struct KdSub<double> { static constexpr int S = 2048, CAP = 256; };
+// Sizes chosen so that two workgroups fit in a CU's 160 KB of LDS (~75 KB / ~63 KB each): with about M/S sub-trees in
+// flight the second round of blocks that a 1-per-CU footprint would cause on 256 CUs is avoided.
+template <> struct KdSub<float>  { static constexpr int S = 2048, CAP = 192; };
+template <> struct KdSub<double> { static constexpr int S = 1024, CAP = 96; };
 constexpr int kSubThreads = 512;
 
 template <typename T>
@@ -331,7 +334,7 @@ __host__ __device__ constexpr size_t kd_sub_lds_bytes() {
            18 * (size_t)KdSub<T>::CAP * sizeof(Enc) + 2 * (size_t)KdSub<T>::CAP * 2 + 6 * (size_t)KdSub<T>::CAP * sizeof(T) + 256;
 }
 
-__device__ __forceinline__ void block_scan2_512(unsigned a, unsigned b2, unsigned& ea, unsigned& eb, unsigned& ta, unsigned& tb, unsigned* s_w /*34 words*/) {
+__device__ __forceinline__ void block_scan2(unsigned a, unsigned b2, unsigned& ea, unsigned& eb, unsigned& ta, unsigned& tb, unsigned* s_w /*34 words*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned ia = a, ib = b2;
 #pragma unroll
@@ -369,6 +372,8 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     T* n_bb = reinterpret_cast<T*>(s_misc + 8);                                // [CAP][6] hand-down boxes of the active nodes
 
     const int root_gid = b.sub_nodes[blockIdx.x];
+    long long t_prev = b.prof ? wall_clock64() : 0;
+#define KD_PROF(slot) do { if (b.prof && blockIdx.x == 0 && threadIdx.x == 0) { long long t_now = wall_clock64(); b.prof[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     KdNode<T>& root = b.nodes[root_gid];
     const int g0 = root.left, n = root.right - root.left;
     const int tid = threadIdx.x;
@@ -403,6 +408,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     int n_act = (n > b.leaf_max) ? 1 : 0;
     const int p0 = tid * IPT;                       // this thread's contiguous positions [p0, p0+IPT)
 
+    KD_PROF(0);
     while (n_act > 0) {
         // S1: leaf test is implied (only nodes with count > leaf_max are active); middleSplit_ head
         if (tid < n_act) {
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
         }
         if (tid == 0) { s_misc[2] = 0; s_misc[0] = 0; }
         __syncthreads();
+        KD_PROF(1);
         // S2: lim1, lim2. Lanes hold consecutive positions, so a wave sees at most a few distinct nodes:
         // one ballot-popcount + one LDS atomic per distinct node instead of two atomics per element.
         for (int base = 0; base < n; base += kSubThreads) {
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
         }
         __syncthreads();
+        KD_PROF(2);
         if (tid < n_act && n_lt[tid] != n_le[tid]) s_misc[2] = 1;      // some element equals its node's cut value
         __syncthreads();
         const int n_ph = s_misc[2] ? 2 : 1;                             // planeSplit's second loop has nothing to move otherwise
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
                 nl += bl[j]; nr += br[j];
             }
             unsigned el, er, tl, tr;
-            block_scan2_512(nl, nr, el, er, tl, tr, s_w);
+            block_scan2(nl, nr, el, er, tl, tr, s_w);
             {   // record the prefixes at node boundaries
                 unsigned rl = el, rr = er;
 #pragma unroll
@@ -498,6 +506,7 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
             __syncthreads();
         }
+        KD_PROF(3);
         // S5: split index, children (ids come from the block's reserved range: no global round trip)
         T cbb[12];                                   // hand-down boxes of this thread's two children, installed in S7
         if (tid < n_act) {
@@ -528,40 +537,57 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
             }
         }
         __syncthreads();
-        // S6: children's tight boxes + re-label elements. Up to two distinct children per wave are reduced with
-        // shuffles (one LDS atomic per value); lanes of further children fall back to per-element LDS atomics.
-        for (int base = 0; base < n; base += kSubThreads) {
-            const int p = base + tid;
-            const int i = p < n ? seg[p] : 0xFFFF;
-            int ck = -1; Pt4<T> v; v.x = v.y = v.z = 0; v.idx = 0;
-            if (i != 0xFFFF) { ck = 2 * i + (p >= n_left[i] + n_idx[i]); v = E[p]; }
-            unsigned long long rem = __ballot(ck >= 0);
-            for (int round = 0; round < 2 && rem; ++round) {
-                const int leader = __ffsll((long long)rem) - 1;
-                const int key = __shfl(ck, leader, 64);
-                const bool mine = ck == key;
-                const unsigned long long m = __ballot(mine);
-                const T lx = wave_min(mine ? v.x : Limits<T>::max_v), hx = wave_max(mine ? v.x : -Limits<T>::max_v);
-                const T ly = wave_min(mine ? v.y : Limits<T>::max_v), hy = wave_max(mine ? v.y : -Limits<T>::max_v);
-                const T lz = wave_min(mine ? v.z : Limits<T>::max_v), hz = wave_max(mine ? v.z : -Limits<T>::max_v);
-                if ((tid & 63) == leader) {
-                    Enc* mm = c_mm + 6 * key;
-                    atomicMin(&mm[0], enc(lx)); atomicMax(&mm[3], enc(hx));
-                    atomicMin(&mm[1], enc(ly)); atomicMax(&mm[4], enc(hy));
-                    atomicMin(&mm[2], enc(lz)); atomicMax(&mm[5], enc(hz));
+        KD_PROF(4);
+        // S6: children's tight boxes + re-label elements. Each thread folds its IPT consecutive positions, then the
+        // wave runs a segmented min/max reduction over lanes (children are contiguous position ranges, so equal
+        // keys are contiguous lanes); the first lane of each segment issues the LDS atomics.
+        {
+            int key = -1;                              // child (2*node + side) of the run this thread is accumulating
+            T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+            auto flush = [&](int k2) {
+                Enc* mm = c_mm + 6 * k2;
+                atomicMin(&mm[0], enc(lo[0])); atomicMax(&mm[3], enc(hi[0]));
+                atomicMin(&mm[1], enc(lo[1])); atomicMax(&mm[4], enc(hi[1]));
+                atomicMin(&mm[2], enc(lo[2])); atomicMax(&mm[5], enc(hi[2]));
+            };
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const int p = p0 + j;
+                const int i = p < n ? seg[p] : 0xFFFF;
+                if (i == 0xFFFF) continue;
+                const int ck = 2 * i + (p >= n_left[i] + n_idx[i]);
+                const Pt4<T> v = E[p];
+                if (ck != key) {                       // a run ended inside this thread's positions: flush it directly
+                    if (key >= 0) flush(key);
+                    key = ck;
+                    lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
+                } else {
+                    lo[0] = v.x < lo[0] ? v.x : lo[0]; hi[0] = v.x > hi[0] ? v.x : hi[0];
+                    lo[1] = v.y < lo[1] ? v.y : lo[1]; hi[1] = v.y > hi[1] ? v.y : hi[1];
+                    lo[2] = v.z < lo[2] ? v.z : lo[2]; hi[2] = v.z > hi[2] ? v.z : hi[2];
                 }
-                if (mine) ck = -2 - ck;            // done (keep the key recoverable for the re-label below)
-                rem &= ~m;
+                seg[p] = child_slot[ck];
             }
-            if (ck >= 0) {
-                Enc* mm = c_mm + 6 * ck;
-                atomicMin(&mm[0], enc(v.x)); atomicMax(&mm[3], enc(v.x));
-                atomicMin(&mm[1], enc(v.y)); atomicMax(&mm[4], enc(v.y));
-                atomicMin(&mm[2], enc(v.z)); atomicMax(&mm[5], enc(v.z));
+            // `key` is the LAST run of this thread; earlier runs were flushed. Lanes with the same key form
+            // contiguous stretches except where a thread's first run differs from its last: treat the pair
+            // (key of first run == key of last run) conservatively by requiring equality with the neighbour's key.
+            const int lane = tid & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int ok = __shfl_down(key, o, 64);
+                T olo[3], ohi[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { olo[d] = __shfl_down(lo[d], o, 64); ohi[d] = __shfl_down(hi[d], o, 64); }
+                if (lane + o < 64 && ok == key && key >= 0) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { lo[d] = olo[d] < lo[d] ? olo[d] : lo[d]; hi[d] = ohi[d] > hi[d] ? ohi[d] : hi[d]; }
+                }
             }
-            if (i != 0xFFFF) seg[p] = child_slot[ck >= 0 ? ck : -2 - ck];
+            const int pk = __shfl_up(key, 1, 64);
+            if (key >= 0 && (lane == 0 || pk != key)) flush(key);      // head of a segment holds its reduction
         }
         __syncthreads();
+        KD_PROF(5);
         // S7: publish children's boxes; install the next level
         const int n_next = s_misc[0];
         for (int cidx = tid; cidx < 2 * n_act; cidx += kSubThreads) {
@@ -583,9 +609,12 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
         if (tid == 0) { s_misc[3] += 2 * n_act; atomicMax(b.max_depth, root_depth + sub_level + 1); }
         n_act = n_next; ++sub_level;
         __syncthreads();
+        KD_PROF(6);
     }
     for (int p = tid; p < n; p += kSubThreads) b.E[g0 + p] = E[p];
     if (tid == 0 && s_misc[3]) atomicAdd(b.n_real, s_misc[3]);
+    KD_PROF(7);
+#undef KD_PROF
 }
 
 // ---- nanoflann search for the tied queries ---------------------------------------------------------------------------

@@ -272,6 +272,8 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     *err_out = counters + 3;
     b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
     b.n_cur = counters + 7; b.n_next = counters + 8;
+    b.prof = nullptr;
+    if (getenv("PCU_HIP_PROF_KD")) { if (aalloc(ar, &b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
@@ -324,6 +326,10 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *levels_out = hcnt[5] + 1;      // tree depth (root = 0) + 1
+    if (b.prof) {
+        long long hp[16]; HIP_TRY(hipMemcpy(hp, b.prof, sizeof hp, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[kd prof] n_sub=%d nodes=%d depth=%d | ticks(100MHz): load %lld S1 %lld S2 %lld S3/4 %lld S5 %lld S6 %lld S7 %lld store %lld\n", n_sub, hcnt[6], hcnt[5], hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+    }
     if (n_real_out) *n_real_out = hcnt[6];
     return 0;
 }
