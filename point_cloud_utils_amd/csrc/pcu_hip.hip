@@ -45,6 +45,10 @@ struct pcu_hip_ctx {
     int n_kev = 0;
     double occupancy = 0;                      // <=0: default
     int* h_pinned = nullptr;                   // small pinned readback buffer
+    // tie-order resolver: its own grow-only workspace (stable addresses across calls, so the captured
+    // level-pair graph below stays valid) and one cached executable graph per scalar type
+    char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
+    struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[2];
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -64,6 +68,34 @@ struct Arena {
     }
 };
 template <typename U> static int aalloc(Arena& a, U** out, size_t count) { return a.alloc((void**)out, count * sizeof(U)); }
+
+// Bump allocator over the context's kd workspace (grown, never shrunk; growth invalidates the cached graphs).
+struct KdArena {
+    pcu_hip_ctx* c;
+    template <typename U> int get(U** out, size_t count) {
+        size_t bytes = align_up(count * sizeof(U) ? count * sizeof(U) : 16, 256);
+        if (c->kd_ws_off + bytes > c->kd_ws_cap) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd workspace overflow");
+        *out = reinterpret_cast<U*>(c->kd_ws + c->kd_ws_off); c->kd_ws_off += bytes; return 0;
+    }
+};
+static void kd_graph_drop(pcu_hip_ctx* c) {
+    for (auto& g : c->kd_graph) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g = pcu_hip_ctx::KdGraph();
+    }
+}
+static int kd_ws_reserve(pcu_hip_ctx* c, size_t bytes) {
+    if (bytes > c->kd_ws_cap) {
+        kd_graph_drop(c);
+        if (c->kd_ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->kd_ws)); c->kd_ws = nullptr; c->kd_ws_cap = 0; }
+        size_t cap = align_up(bytes + (bytes >> 3), 1 << 20);
+        HIP_TRY(hipMalloc((void**)&c->kd_ws, cap));
+        c->kd_ws_cap = cap;
+    }
+    c->kd_ws_off = 0;
+    return 0;
+}
 
 static void ctx_end(pcu_hip_ctx* c);
 static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
@@ -159,7 +191,7 @@ template <typename T>
 static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s) {
     if (nwork <= 0) return 0;
     dim3 grid((nwork + kBlock - 1) / kBlock), block(kBlock);
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK, MODE_FAST>), grid, block, 0, s, a); break;
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
         PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
@@ -261,52 +293,78 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // node ids: < 2*max_level for the top levels, plus 2n reserved by each LDS sub-tree block (sum of n <= M)
     const size_t max_nodes = 2 * (size_t)M + 4 * max_level + 16;
     const size_t max_items = (size_t)M / kKdChunk + max_level + 2;
+    const size_t n_sub_cap = 2 * max_level + (size_t)M / (size_t)(b.sub_max / 2 + 1) + 16;
     int* counters = nullptr;
-    if (aalloc(ar, &b.E, (size_t)M) || aalloc(ar, &b.nodes, max_nodes) || aalloc(ar, &counters, 16)) return -1;
-    if (aalloc(ar, &b.level_nodes, max_level) || aalloc(ar, &b.next_nodes, max_level)) return -1;
-    if (aalloc(ar, &b.level_cbase, max_level + 1) || aalloc(ar, &b.next_cbase, max_level + 1)) return -1;
-    if (aalloc(ar, &b.chunk_bl, max_items) || aalloc(ar, &b.chunk_br, max_items)) return -1;
-    if (aalloc(ar, &b.BLpos, (size_t)M) || aalloc(ar, &b.BRpos, (size_t)M)) return -1;
-    if (aalloc(ar, &b.sub_nodes, 2 * max_level + (size_t)M / (size_t)(b.sub_max / 2 + 1) + 16)) return -1;
+    (void)ar;
+    {
+        auto al = [](size_t v) { return align_up(v, 256); };
+        const size_t need = al((size_t)M * sizeof(Pt4<T>)) + al(max_nodes * sizeof(KdNode<T>)) + al(64) + 2 * al(max_level * 4) +
+                            2 * al((max_level + 1) * 4) + 2 * al(max_items * 4) + 2 * al((size_t)M * 4) + al(n_sub_cap * 4) + al(16 * 8) + 4096;
+        if (kd_ws_reserve(c, need)) return -1;
+    }
+    KdArena ka{c};
+    if (ka.get(&b.E, (size_t)M) || ka.get(&b.nodes, max_nodes) || ka.get(&counters, 16)) return -1;
+    if (ka.get(&b.level_nodes, max_level) || ka.get(&b.next_nodes, max_level)) return -1;
+    if (ka.get(&b.level_cbase, max_level + 1) || ka.get(&b.next_cbase, max_level + 1)) return -1;
+    if (ka.get(&b.chunk_bl, max_items) || ka.get(&b.chunk_br, max_items)) return -1;
+    if (ka.get(&b.BLpos, (size_t)M) || ka.get(&b.BRpos, (size_t)M)) return -1;
+    if (ka.get(&b.sub_nodes, n_sub_cap)) return -1;
     b.n_nodes = counters; b.n_items = counters + 2;
     *err_out = counters + 3;
     b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
     b.n_cur = counters + 7; b.n_next = counters + 8;
     b.prof = nullptr;
-    if (getenv("PCU_HIP_PROF_KD")) { if (aalloc(ar, &b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
+    if (getenv("PCU_HIP_PROF_KD")) { if (ka.get(&b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
-    const bool dbg = getenv("PCU_HIP_DEBUG_KD") != nullptr;
     const int items_ub = (int)max_items;
-    // The number of nodes per level lives on the device; kernels of an exhausted level exit at once. Levels are
-    // therefore enqueued in batches without any host round trip: first the expected log2(M / sub_max) + 2, then 4
-    // at a time until the device reports an empty level.
+    // One level = 9 short launches; the count of nodes per level lives on the device and kernels of an exhausted
+    // level exit at once, so levels need no host decision. Two consecutive levels (the ping-pong of the level
+    // lists has period 2) are captured ONCE into a hipGraph and replayed: the expected log2(M / sub_max) + 2
+    // levels first, then two at a time until the device reports an empty level. Replay removes most of the
+    // per-launch host cost, which dominated this launch-bound phase.
+    auto enqueue_level_pair = [&](KdBuild<T> bb) {
+        for (int half = 0; half < 2; ++half) {
+            hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
+            hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
+            for (int ph = 0; ph < 2; ++ph) {
+                hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+                hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+                hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+            }
+            hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, bb);
+            std::swap(bb.level_nodes, bb.next_nodes);
+            std::swap(bb.level_cbase, bb.next_cbase);
+            std::swap(bb.n_cur, bb.n_next);
+        }
+    };
     int expected = 2;
     for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
     int hcnt[16];
-    int level = 0;
-    for (int batch = M > b.sub_max ? expected : 0; batch > 0; batch = 4) {
-        for (int i = 0; i < batch; ++i, ++level) {
-#define KD_STEP(name, ...) do { __VA_ARGS__; if (dbg) { hipError_t e_ = hipStreamSynchronize(s); fprintf(stderr, "[kd] level %d %s -> %s\n", level, name, hipGetErrorString(e_)); } } while (0)
-            KD_STEP("minmax", hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
-            KD_STEP("count", hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b));
-            for (int ph = 0; ph < 2; ++ph) {
-                KD_STEP("bad_count", hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-                KD_STEP("lists", hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-                KD_STEP("swap", hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, b, ph));
-            }
-            KD_STEP("advance", hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, b));
-#undef KD_STEP
-            std::swap(b.level_nodes, b.next_nodes);
-            std::swap(b.level_cbase, b.next_cbase);
-            std::swap(b.n_cur, b.n_next);
+    if (M > b.sub_max) {
+        auto& G = c->kd_graph[sizeof(T) == 4 ? 0 : 1];
+        const bool use_graph = getenv("PCU_HIP_NO_GRAPH") == nullptr;
+        if (use_graph && (!G.exec || G.key_ptr != (const void*)b.E || G.key_m != M || G.key_leaf != leaf_max)) {
+            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+            if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
+            HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            enqueue_level_pair(b);
+            HIP_TRY(hipStreamEndCapture(s, &G.graph));
+            HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+            G.key_ptr = (const void*)b.E; G.key_m = M; G.key_leaf = leaf_max;
         }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (hcnt[b.n_cur - counters] == 0) break;
-        if (level > 100000) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order build does not terminate");
+        int pairs = (expected + 1) / 2;
+        for (int guard = 0; guard < 100000; ++guard) {
+            for (int i = 0; i < pairs; ++i) {
+                if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (hcnt[b.n_cur - counters] == 0) break;      // after an even number of levels the roles are as at the start
+            pairs = 1;
+        }
     }
     (void)c;
     // finish every small node inside one workgroup's LDS
@@ -731,6 +789,8 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     (void)hipDeviceSynchronize();
     ctx_end(c);
     if (c->arena) (void)hipFree(c->arena);
+    kd_graph_drop(c);
+    if (c->kd_ws) (void)hipFree(c->kd_ws);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);

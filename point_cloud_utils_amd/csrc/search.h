@@ -29,8 +29,6 @@
 
 namespace pcu {
 
-enum { MODE_FAST = 0, MODE_LEX = 1 };
-
 template <typename T>
 struct SearchArgs {
     const GridParams<T>* gp;        // dataset grid
@@ -101,7 +99,36 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
     return lb;
 }
 
-template <typename T, int K, int MODE>
+// Offer one candidate to a lane's K best (ascending d2, registers). Ties are only *detected* here: an equal d2 that
+// is rejected at the k-th slot, or an evicted element equal to the new k-th, raises `tie`.
+template <typename T, int K>
+__device__ __forceinline__ void offer(const T d, const int id, T (&bd)[K], int (&bi)[K], bool& tie) {
+    if (d < bd[K - 1]) {
+        const T ev = bd[K - 1];
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+            const bool gm = bd[i - 1] > d;
+            const bool gi = bd[i] > d;
+            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+        }
+        if (bd[0] > d || K == 1) { bd[0] = d; bi[0] = id; }
+        if (K > 1 && ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;
+    } else if (d == bd[K - 1]) {
+        tie = true;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
+    const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
+    return ((dx * dx) + (dy * dy)) + (dz * dz);
+}
+
+// Main pass: radius R = 1 (the 27 cells around the query's cell). The 9 row bounds are fetched up front (18
+// independent loads in flight), then each row is consumed in groups of 4 candidates whose 4 loads are issued
+// together, so a lane exposes ~20 dependent memory latencies instead of ~70.
+template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
@@ -110,14 +137,13 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int R = a.R;
 
     const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
     const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
     const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
-    const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
-    const int y0 = max(ccy - R, 0), y1 = min(ccy + R, Gy - 1);
-    const int z0 = max(ccz - R, 0), z1 = min(ccz + R, Gz - 1);
+    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
+    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
+    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
 
     T bd[K];
     int bi[K];
@@ -125,49 +151,27 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
     bool tie = false;
 
-    // centre-out over rows: near rows first so the k-th best shrinks early (fewer insertions for K > 1)
-    for (int iz = 0; iz <= 2 * R; ++iz) {
-        const int cz = ccz + ((iz & 1) ? -((iz + 1) >> 1) : (iz >> 1));
-        if (cz < z0 || cz > z1) continue;
-        for (int iy = 0; iy <= 2 * R; ++iy) {
-            const int cy = ccy + ((iy & 1) ? -((iy + 1) >> 1) : (iy >> 1));
-            if (cy < y0 || cy > y1) continue;
-            const int row = (cz * Gy + cy) * Gx;
-            const unsigned s = a.cell_start[row + x0], e = a.cell_start[row + x1 + 1];
-            for (unsigned p = s; p < e; ++p) {
-                const Pt4<T> r = a.ref[p];
-                const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
-                const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
-                const int id = (int)r.idx;
-                if (MODE == MODE_FAST) {
-                    if (d < bd[K - 1]) {
-                        const T ev = bd[K - 1];
+    unsigned rs[9], re[9];                 // rows centre-out: near rows first so the k-th best shrinks early
 #pragma unroll
-                        for (int i = K - 1; i > 0; --i) {
-                            const bool gm = bd[i - 1] > d;
-                            const bool gi = bd[i] > d;
-                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
-                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
-                        }
-                        if (bd[0] > d || K == 1) { bd[0] = d; bi[0] = id; }
-                        if (K > 1 && ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;   // evicted one equals the new k-th
-                    } else if (d == bd[K - 1]) {
-                        tie = true;                                                       // rejected one equals the k-th
-                    }
-                } else {
-                    const bool lt_last = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
-                    if (lt_last) {
+    for (int j = 0; j < 9; ++j) {
+        const int oy = (j % 3 == 0) ? 0 : ((j % 3 == 1) ? -1 : 1), oz = (j / 3 == 0) ? 0 : ((j / 3 == 1) ? -1 : 1);
+        const int cy = ccy + oy, cz = ccz + oz;
+        const bool ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
+        const int row = ((ok ? cz : ccz) * Gy + (ok ? cy : ccy)) * Gx;
+        rs[j] = a.cell_start[row + x0];
+        const unsigned e = a.cell_start[row + x1 + 1];
+        re[j] = ok ? e : rs[j];
+    }
 #pragma unroll
-                        for (int i = K - 1; i > 0; --i) {
-                            const bool gm = bd[i - 1] > d || (bd[i - 1] == d && bi[i - 1] > id);
-                            const bool gi = bd[i] > d || (bd[i] == d && bi[i] > id);
-                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
-                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
-                        }
-                        if (K == 1 || bd[0] > d || (bd[0] == d && bi[0] > id)) { bd[0] = d; bi[0] = id; }
-                    }
-                }
-            }
+    for (int j = 0; j < 9; ++j) {
+        const unsigned e = re[j];
+        for (unsigned p = rs[j]; p < e; p += 4) {
+            const unsigned last = e - 1;
+            const Pt4<T> c0 = a.ref[p], c1 = a.ref[min(p + 1, last)], c2 = a.ref[min(p + 2, last)], c3 = a.ref[min(p + 3, last)];
+            offer<T, K>(dist2(q, c0), (int)c0.idx, bd, bi, tie);
+            if (p + 1 < e) offer<T, K>(dist2(q, c1), (int)c1.idx, bd, bi, tie);
+            if (p + 2 < e) offer<T, K>(dist2(q, c2), (int)c2.idx, bd, bi, tie);
+            if (p + 3 < e) offer<T, K>(dist2(q, c3), (int)c3.idx, bd, bi, tie);
         }
     }
 
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 #pragma unroll
         for (int i = 1; i < K; ++i)
             if (i <= kreq && bd[i] == bd[i - 1] && bi[i] != 0x7fffffff) adj = true;
-        if (MODE == MODE_FAST) tie = tie || adj; else tie = adj;
+        tie = tie || adj;
     }
     wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
     wave_append(certified && tie, qpos, a.ties, a.n_ties);
