@@ -190,7 +190,7 @@ constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes
 template <typename T>
 static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s) {
     if (nwork <= 0) return 0;
-    dim3 grid((nwork + kBlock - 1) / kBlock), block(kBlock);
+    dim3 grid((((nwork + kBlock - 1) / kBlock) + 7) / 8 * 8), block(kBlock);     // multiple of 8: XCD-aware block map
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
         PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64)
@@ -240,6 +240,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     double occ = 1.5;
     int k = 1; bool squared = false;
     int leaf_max = 10; bool tie_order = true;   // reference's max_points_per_leaf: defines the order of exact ties
+    int n_tt = 0;                               // genuine-tie queries found (filled by search_finish)
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
 };
@@ -427,6 +428,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     int n_left = hc[C_U3];
     if (n_left == 0) {
         if (st) st->n_tie_true += hc[C_TT];
+        j.n_tt = hc[C_TT];
         if (hc[C_TT] > 0 && j.tie_order) { if (tie_order_resolve(c, ar, s, j, hc[C_TT], st)) return -1; return 1; }
         return 0;
     }
@@ -467,6 +469,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     int tt = 0;
     HIP_TRY(hipMemcpy(&tt, j.sc.counters + C_TT, sizeof(int), hipMemcpyDeviceToHost));
     if (st) st->n_tie_true += tt;
+    j.n_tt = tt;
     if (tt > 0 && j.tie_order && tie_order_resolve(c, ar, s, j, tt, st)) return -1;
     return 1;
 }
@@ -591,9 +594,9 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
 template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
                       bool squared, double occ, long long* ext_cxy, long long* ext_cyx, PairState<T>& P, Timer& tm,
-                      pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order) {
+                      pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx) {
     P.two = two_sided;
-    P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = P.yx.tie_order = tie_order;
+    P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = tie_order_xy; P.yx.tie_order = tie_order_yx;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
@@ -656,7 +659,7 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     int rc = 0;
     do {
         PairState<T> P;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided, max_leaf, !(flags & PCU_HIP_NO_TIE_ORDER)))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided, max_leaf, false, false))) break;
         ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
@@ -666,6 +669,31 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
             else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
         }
         if (rc) break;
+        // The value never depends on the order of exact ties, and (i, j) only does if the arg-max source row i itself
+        // has tied nearest neighbours: only then is that direction's tie order resolved (kd_order.h) and j re-read.
+        if (!(flags & PCU_HIP_NO_TIE_ORDER)) {
+            bool redo = false;
+            for (int dir = 0; dir < (two_sided ? 2 : 1) && !rc; ++dir) {
+                SearchJob<T>& J = dir ? P.yx : P.xy;
+                if (J.n_tt <= 0) continue;
+                std::vector<int> tq((size_t)J.n_tt);
+                HIP_TRY(hipMemcpy(tq.data(), J.sc.tt, (size_t)J.n_tt * sizeof(int), hipMemcpyDeviceToHost));
+                bool hit = false;
+                for (int qpos : tq) {
+                    Pt4<T> e; HIP_TRY(hipMemcpy(&e, J.qidx.sorted + qpos, sizeof e, hipMemcpyDeviceToHost));
+                    if ((long long)e.idx == host.ij[2 * dir]) { hit = true; break; }
+                }
+                if (hit) { if (tie_order_resolve(c, ar, s, J, J.n_tt, st)) { rc = -1; break; } redo = true; }
+            }
+            if (rc) break;
+            if (redo) {
+                if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
+                if (two_sided && (rc = argmax_enqueue(s, P.yx, P, 1))) break;
+                HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                memcpy(&host, c->h_pinned, sizeof host);
+            }
+        }
         const T* hv = reinterpret_cast<const T*>(host.vals); const long long* hij = host.ij;
         const int nres = two_sided ? 2 : 1;
         for (int r = 0; r < nres; ++r) { out_d[r] = hv[r]; out_i[r] = hij[2 * r]; out_j[r] = hij[2 * r + 1]; }
@@ -700,7 +728,11 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         PairState<T> P;
         long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
         long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, max_leaf, !(flags & PCU_HIP_NO_TIE_ORDER)))) break;
+        // Which of two exactly tied neighbours is picked changes a direction's contribution only through the returned
+        // indices, or through a p != 2 norm of the difference vector; the p = 2 value is the tied distance itself.
+        const bool tie_any = !(flags & PCU_HIP_NO_TIE_ORDER);
+        const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, max_leaf, tie_xy, tie_yx))) break;
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
         const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);

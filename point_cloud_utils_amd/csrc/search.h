@@ -130,7 +130,13 @@ __device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
 // together, so a lane exposes ~20 dependent memory latencies instead of ~70.
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    // XCD-aware block order: workgroup b is dispatched to XCD b % 8 (observed placement; speed only, never
+    // correctness). Queries are in spatial (cell) order, so giving each XCD one CONTIGUOUS eighth of the blocks
+    // makes every XCD's private L2 hold one eighth of the dataset (+halo) instead of all of it.
+    // (the launcher rounds the grid up to a multiple of 8, so the map below is a bijection of the block ids)
+    const int per = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int t = vb * kBlock + threadIdx.x;
     const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
     if (t >= nq) return;
     const int qpos = a.qlist ? a.qlist[t] : t;

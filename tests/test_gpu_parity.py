@@ -267,3 +267,25 @@ def test_batched_single_rank(pcu, oracle_kind):
         x, y = get_pair(p)
         assert tuple(hd[p]) == oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind)
         assert abs(ch[p] - float(oracle.chamfer_distance(x, y, kind=oracle_kind))) <= 1e-4 * ch[p]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_metrics_under_exact_ties(pcu, oracle_kind, dtype):
+    """Lattice data: nearly every nearest neighbour is exactly tied. Values never depend on tie order; returned
+    indices (Hausdorff (i, j) of the arg-max row, Chamfer correspondences, p != 2 norms) follow the kd-tree order."""
+    rng = np.random.default_rng(4)
+    y = np.stack(np.meshgrid(*[np.arange(11)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(dtype)
+    x = (rng.integers(0, 22, (3000, 3)) / 2).astype(dtype)
+    for a, b in ((x, y), (y, x)):
+        assert pcu.hausdorff_distance(a, b, return_index=True) == oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind)
+        assert pcu.one_sided_hausdorff_distance(a, b) == oracle.one_sided_hausdorff_distance(a, b, kind=oracle_kind)
+        assert pcu.hausdorff_distance(a, b) == oracle.hausdorff_distance(a, b, kind=oracle_kind)
+    ch, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    tol = 1e-4 if dtype == np.float32 else 1e-6
+    assert abs(float(ch) - float(ch0)) <= tol * float(ch0)
+    assert abs(float(pcu.chamfer_distance(x, y)) - float(ch0)) <= tol * float(ch0)      # value-only path (no tie resolution needed)
+    for p in (1, np.inf, 0.5):
+        v, v0 = pcu.chamfer_distance(x, y, p_norm=p), oracle.chamfer_distance(x, y, p_norm=p, kind=oracle_kind)
+        assert abs(float(v) - float(v0)) <= tol * float(v0), p
