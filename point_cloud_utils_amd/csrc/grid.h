@@ -2,7 +2,7 @@
 //
 // Replaces the role of the reference's kd-tree *build* (nanoflann.hpp:1363-1375 buildIndex / :1001-1059
 // divideTree, which pcu runs three times per call: src/point_cloud_distance.cpp:41-42) with a counting sort of
-// the cloud into x-fastest grid-cell order. The grid only decides which candidates a query evaluates; it has
+// the cloud into snake (boustrophedon) grid-cell order. The grid only decides which candidates a query evaluates; it has
 // no influence on results, which depend only on the distance arithmetic in search.h.
 //
 // Pipeline (all on one stream, no host round trip; grid shape lives in device memory):
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int
     const int cx = cell_coord(x, gp->gmin[0], gp->inv_h, gp->G[0]);
     const int cy = cell_coord(y, gp->gmin[1], gp->inv_h, gp->G[1]);
     const int cz = cell_coord(z, gp->gmin[2], gp->inv_h, gp->G[2]);
-    const unsigned c = (unsigned)((cz * gp->G[1] + cy) * gp->G[0] + cx);
+    const unsigned c = (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], cy, cz), cx, cx);
     cell_of[i] = c;
     rank[i] = atomicAdd(&counts[c], 1u);
 }

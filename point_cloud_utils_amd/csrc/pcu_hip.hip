@@ -37,6 +37,9 @@ static int fail(int code, const char* fmt, ...) {
 struct pcu_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;          // second lane for two-sided ops: the two clouds' index builds and the two
+                                               // search directions are independent and latency-bound, so they overlap
+    hipEvent_t jev[4] = {};                    // fork/join events between the caller's stream and aux_stream
     char* arena = nullptr; size_t arena_cap = 0, arena_off = 0;
     std::vector<void*> extra;                 // overflow allocations of the current call
     size_t extra_bytes = 0;
@@ -190,8 +193,15 @@ constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes
 template <typename T>
 static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s) {
     if (nwork <= 0) return 0;
-    dim3 grid((((nwork + kBlock - 1) / kBlock) + 7) / 8 * 8), block(kBlock);     // multiple of 8: XCD-aware block map
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
+    // grid = multiple of 8 (XCD-aware block map). Default: the per-lane gather kernel; PCU_HIP_TILE=1 selects the
+    // LDS-tiled kernel (one wave per block). Measured on MI355X (profiles/r01_search_kernel_ab.txt): both are
+    // instruction-issue bound at ~2-3k instructions per wave; the tile kernel issues 15x fewer vector memory
+    // instructions but more VALU/SALU/LDS bookkeeping and is slower (129 vs 83 us at 1M/k=1), so gather stays default.
+    static const bool use_gather = getenv("PCU_HIP_TILE") == nullptr;
+    const int tb = use_gather ? kBlock : 64;
+    dim3 grid((((nwork + tb - 1) / tb) + 7) / 8 * 8), block(tb);
+#define PCU_CASE(KK) case KK: if (use_gather) hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); \
+                              else hipLaunchKernelGGL((k_search_tile<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
         PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
@@ -613,11 +623,20 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
     tm.mark(0);
-    if (index_build(ix, P.dx, occ, s) || index_build(iy, P.dy, occ, s)) return -1;
+    // fork: cloud y is indexed on the aux stream while cloud x is indexed on s
+    // (measured: the passes are throughput-bound, so the overlap only buys ~3 %; off unless PCU_HIP_TWO_STREAMS is set)
+    hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
+    if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
+    if (index_build(ix, P.dx, occ, s) || index_build(iy, P.dy, occ, s2)) return -1;
+    if (s2 != s) {      // both searches need both indices
+        HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
+        HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
+    }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
     if (search_enqueue(c, s, P.xy, st)) return -1;
-    if (two_sided && search_enqueue(c, s, P.yx, st)) return -1;
+    if (two_sided && search_enqueue(c, s2, P.yx, st)) return -1;
+    if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[3], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[3], 0)); }   // join
     tm.mark(2);
     return 0;
 }
@@ -809,6 +828,8 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
@@ -827,6 +848,8 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (auto& e : c->jev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 int pcu_hip_ctx_set_cell_occupancy(pcu_hip_ctx* c, double ppc) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->occupancy = ppc; return 0; }

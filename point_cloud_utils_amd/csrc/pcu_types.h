@@ -59,4 +59,12 @@ __device__ __forceinline__ int cell_coord(T v, T gmin, T inv_h, int G) {
     return (t >= (T)0) ? ((t < (T)G) ? (int)t : G - 1) : 0;
 }
 
+// Cell order: boustrophedon ("snake"). Rows (y,z) are numbered z-major with y reversed on odd z, and cells inside
+// a row run in +x on even rows and -x on odd rows, so consecutive cells of the linear order are always face
+// neighbours: 64 consecutive points of a cell-ordered cloud form a compact snake instead of wrapping around the
+// grid at row ends. The cells [xa..xb] of one row are still one contiguous run of the linear order.
+__device__ __forceinline__ int grid_row(int Gy, int cy, int cz) { return cz * Gy + ((cz & 1) ? Gy - 1 - cy : cy); }
+// linear index of the first cell of the run covering cells xa..xb (xa <= xb) of row `row`
+__device__ __forceinline__ int row_run_lo(int Gx, int row, int xa, int xb) { return row * Gx + ((row & 1) ? Gx - 1 - xb : xa); }
+
 }  // namespace pcu

@@ -5,7 +5,8 @@
 //
 // One lane = one query, processed in the *query cloud's own cell order* so that the 64 lanes of a wave look at
 // the same few rows of dataset cells (L1/L2-resident). A lane scans the (2R+1)^3 block of cells around its
-// own cell, row by row: the cells [x0..x1] of one (y,z) row are one contiguous run of `sorted` records.
+// own cell, row by row: the cells [x0..x1] of one (y,z) row are one contiguous run of `sorted` records
+// (snake cell order, pcu_types.h).
 //
 // Arithmetic contract (bit parity with the reference):
 //   d2 = ((dx*dx) + (dy*dy)) + (dz*dz),  dx = q.x - r.x, ...   all in T, no FMA (TU built with
@@ -99,10 +100,24 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
     return lb;
 }
 
+template <typename T>
+__device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
+    const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
+    return ((dx * dx) + (dy * dy)) + (dz * dz);
+}
+
 // Offer one candidate to a lane's K best (ascending d2, registers). Ties are only *detected* here: an equal d2 that
 // is rejected at the k-th slot, or an evicted element equal to the new k-th, raises `tie`.
 template <typename T, int K>
 __device__ __forceinline__ void offer(const T d, const int id, T (&bd)[K], int (&bi)[K], bool& tie) {
+    if (K == 1) {                          // branch-free: two compares, two selects
+        tie = tie || (d == bd[0]);
+        const bool lt = d < bd[0];
+        bd[0] = lt ? d : bd[0];
+        bi[0] = lt ? id : bi[0];
+        return;
+    }
+    tie = tie || (d == bd[K - 1]);         // rejected (or about to tie with) the k-th
     if (d < bd[K - 1]) {
         const T ev = bd[K - 1];
 #pragma unroll
@@ -112,17 +127,62 @@ __device__ __forceinline__ void offer(const T d, const int id, T (&bd)[K], int (
             bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
             bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
         }
-        if (bd[0] > d || K == 1) { bd[0] = d; bi[0] = id; }
-        if (K > 1 && ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;
-    } else if (d == bd[K - 1]) {
-        tie = true;
+        if (bd[0] > d) { bd[0] = d; bi[0] = id; }
+        if (ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;      // evicted one equals the new k-th
     }
 }
 
-template <typename T>
-__device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
-    const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
-    return ((dx * dx) + (dy * dy)) + (dz * dz);
+// Candidates are consumed four at a time; slots past the end of the range get all exponent bits set (+inf or NaN),
+// which compares false with both `<` and `==`, so they can never be selected or flagged. Done with integer OR so
+// that the group stays straight-line code (a `?:` on the distance makes the compiler branch around the loads).
+__device__ __forceinline__ float kill_if(float d, bool dead) { return __uint_as_float(__float_as_uint(d) | (dead ? 0x7f800000u : 0u)); }
+__device__ __forceinline__ double kill_if(double d, bool dead) {
+    return __longlong_as_double(__double_as_longlong(d) | (dead ? 0x7ff0000000000000ll : 0ll));
+}
+template <typename T, int K>
+__device__ __forceinline__ void offer4(const Pt4<T>& q, const Pt4<T>& c0, const Pt4<T>& c1, const Pt4<T>& c2, const Pt4<T>& c3,
+                                       unsigned p, unsigned e, T (&bd)[K], int (&bi)[K], bool& tie) {
+    const T d0 = dist2(q, c0);
+    const T d1 = kill_if(dist2(q, c1), p + 1 >= e);
+    const T d2 = kill_if(dist2(q, c2), p + 2 >= e);
+    const T d3 = kill_if(dist2(q, c3), p + 3 >= e);
+    offer<T, K>(d0, (int)c0.idx, bd, bi, tie);
+    offer<T, K>(d1, (int)c1.idx, bd, bi, tie);
+    offer<T, K>(d2, (int)c2.idx, bd, bi, tie);
+    offer<T, K>(d3, (int)c3.idx, bd, bi, tie);
+}
+
+// Certification, output and list appends of one lane (shared by the gather and the LDS-tile main passes).
+// `valid` is false for padding lanes of a partial wave (they only take part in the wave-wide list appends).
+template <typename T, int K>
+__device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridParams<T>& g, const Pt4<T>& q, int qpos,
+                                            int x0, int x1, int y0, int y1, int z0, int z1, T (&bd)[K], int (&bi)[K], bool tie, bool valid) {
+    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const int kreq = a.kreq;
+    T kth = bd[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) if (i == kreq - 1) kth = bd[i];
+    const bool certified = valid && kth < lb;
+
+    if (certified) {
+        const size_t o = (size_t)q.idx * (size_t)kreq;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (i < kreq) {
+                const bool found = bi[i] != 0x7fffffff;
+                a.out_i[o + i] = found ? (long long)bi[i] : -1ll;
+                a.out_d[o + i] = found ? (a.squared ? bd[i] : sqrt(bd[i])) : (T)-1;
+            }
+        }
+        // equal neighbours inside the first kreq(+1) slots
+        bool adj = false;
+#pragma unroll
+        for (int i = 1; i < K; ++i)
+            if (i <= kreq && bd[i] == bd[i - 1] && bi[i] != 0x7fffffff) adj = true;
+        tie = tie || adj;
+    }
+    wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+    wave_append(certified && tie, qpos, a.ties, a.n_ties);
 }
 
 // Main pass: radius R = 1 (the 27 cells around the query's cell). The 9 row bounds are fetched up front (18
@@ -163,9 +223,9 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
         const int oy = (j % 3 == 0) ? 0 : ((j % 3 == 1) ? -1 : 1), oz = (j / 3 == 0) ? 0 : ((j / 3 == 1) ? -1 : 1);
         const int cy = ccy + oy, cz = ccz + oz;
         const bool ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
-        const int row = ((ok ? cz : ccz) * Gy + (ok ? cy : ccy)) * Gx;
-        rs[j] = a.cell_start[row + x0];
-        const unsigned e = a.cell_start[row + x1 + 1];
+        const int lo = row_run_lo(Gx, grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz), x0, x1);
+        rs[j] = a.cell_start[lo];
+        const unsigned e = a.cell_start[lo + (x1 - x0 + 1)];
         re[j] = ok ? e : rs[j];
     }
 #pragma unroll
@@ -174,39 +234,140 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
         for (unsigned p = rs[j]; p < e; p += 4) {
             const unsigned last = e - 1;
             const Pt4<T> c0 = a.ref[p], c1 = a.ref[min(p + 1, last)], c2 = a.ref[min(p + 2, last)], c3 = a.ref[min(p + 3, last)];
-            offer<T, K>(dist2(q, c0), (int)c0.idx, bd, bi, tie);
-            if (p + 1 < e) offer<T, K>(dist2(q, c1), (int)c1.idx, bd, bi, tie);
-            if (p + 2 < e) offer<T, K>(dist2(q, c2), (int)c2.idx, bd, bi, tie);
-            if (p + 3 < e) offer<T, K>(dist2(q, c3), (int)c3.idx, bd, bi, tie);
+            offer4<T, K>(q, c0, c1, c2, c3, p, e, bd, bi, tie);
         }
     }
 
-    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
-    const int kreq = a.kreq;
-    T kth = bd[0];
-#pragma unroll
-    for (int i = 1; i < K; ++i) if (i == kreq - 1) kth = bd[i];
-    const bool certified = kth < lb;
+    finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true);
+}
 
-    if (certified) {
-        const size_t o = (size_t)q.idx * (size_t)kreq;
+// -------------------------------------------------------------------------------------------------------
+// Main pass, LDS-tiled (the default): ONE WAVE = 64 consecutive queries of the cell-ordered query cloud, i.e. a
+// compact snake of query cells. The wave takes the bounding box of its lanes' dataset cells (+1 cell), and for
+// that box
+//   1. loads the box's slice of `cell_start` (one coalesced load per (y,z) row) into LDS,
+//   2. copies the box's dataset records into LDS with coalesced 16-byte loads (a row of the box is one contiguous
+//      run of `sorted`), in groups of rows that fit the wave's LDS slice,
+//   3. lets every lane scan ITS OWN 27 cells out of LDS (ds_read_b128 per candidate, query in registers).
+// Every dataset record the wave needs is thus fetched from L2/HBM exactly once per wave by a wide coalesced load
+// instead of ~3 times by scattered 16-byte per-lane gathers (the gather kernel k_search is TA/L1-throughput
+// bound). Waves whose box does not fit the tables (very uneven data) fall back to the gather code, rows that do
+// not fit the record buffer are gathered from global memory by the lanes; results are identical either way.
+constexpr int kTileNX = 48;        // max cells per box row  (+1 prefix entry)
+constexpr int kTileNR = 16;        // max (y,z) rows per box
+template <typename T> struct TileCap { static constexpr int refs = sizeof(T) == 4 ? 640 : 320; };   // records per LDS slice (10 KB)
+
+template <typename T, int K>
+__device__ __forceinline__ void scan_range(const Pt4<T>* __restrict__ base, unsigned s, unsigned e, const Pt4<T>& q,
+                                           T (&bd)[K], int (&bi)[K], bool& tie) {
+    for (unsigned p = s; p < e; p += 4) {
+        const unsigned last = e - 1;
+        const Pt4<T> c0 = base[p], c1 = base[min(p + 1, last)], c2 = base[min(p + 2, last)], c3 = base[min(p + 3, last)];
+        offer4<T, K>(q, c0, c1, c2, c3, p, e, bd, bi, tie);
+    }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
+    __shared__ __attribute__((aligned(16))) Pt4<T> s_ref[TileCap<T>::refs];
+    __shared__ unsigned s_cs[kTileNR][kTileNX + 1];
+    __shared__ unsigned s_rowbase[kTileNR + 1];
+    // XCD-aware block order (see k_search): each XCD works on one contiguous eighth of the cell-ordered queries
+    const int per = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int lane = threadIdx.x;
+    const int nq = a.nq;
+    const int t0 = vb * 64;
+    if (t0 >= nq) return;
+    const bool valid = t0 + lane < nq;
+    const int qpos = valid ? t0 + lane : nq - 1;            // padding lanes mirror the last query (no effect on the box)
+    const Pt4<T> q = a.qsorted[qpos];
+    const GridParams<T>& g = *a.gp;
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
+    const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
+    const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
+    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
+    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
+    // wave box
+    int X0 = x0, X1 = x1, Y0 = y0, Y1 = y1, Z0 = z0, Z1 = z1;
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            if (i < kreq) {
-                const bool found = bi[i] != 0x7fffffff;
-                a.out_i[o + i] = found ? (long long)bi[i] : -1ll;
-                a.out_d[o + i] = found ? (a.squared ? bd[i] : sqrt(bd[i])) : (T)-1;
+    for (int o = 32; o > 0; o >>= 1) {
+        X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
+        Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
+        Z0 = min(Z0, __shfl_xor(Z0, o, 64)); Z1 = max(Z1, __shfl_xor(Z1, o, 64));
+    }
+    const int nx = X1 - X0 + 1, ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
+
+    T bd[K];
+    int bi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
+    bool tie = false;
+
+    if (nx > kTileNX || nrows > kTileNR) {
+        // box too large for the tables: plain per-lane gather from global memory
+        for (int cz = z0; cz <= z1; ++cz)
+            for (int cy = y0; cy <= y1; ++cy) {
+                const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
+                scan_range<T, K>(a.ref, a.cell_start[lo], a.cell_start[lo + (x1 - x0 + 1)], q, bd, bi, tie);
             }
+    } else {
+        // 1. the box's slice of cell_start: row r = (cz - Z0) * ny + (cy - Y0), entries for cells X0 .. X1+1
+        for (int r = 0; r < nrows; ++r) {
+            const int lo = row_run_lo(Gx, grid_row(Gy, Y0 + r % ny, Z0 + r / ny), X0, X1);
+            if (lane <= nx) s_cs[r][lane] = a.cell_start[lo + lane];
         }
-        // equal neighbours inside the first kreq(+1) slots
-        bool adj = false;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 2./3. groups of consecutive rows whose records fit the LDS slice
+        int r0 = 0;
+        while (r0 < nrows) {
+            // greedy group [r0, r1): lane r holds the size of row r0 + r, inclusive scan, count rows that fit
+            const int rr = r0 + lane;
+            const unsigned cnt = (rr < nrows) ? s_cs[rr][nx] - s_cs[rr][0] : 0u;
+            unsigned inc = cnt;
 #pragma unroll
-        for (int i = 1; i < K; ++i)
-            if (i <= kreq && bd[i] == bd[i - 1] && bi[i] != 0x7fffffff) adj = true;
-        tie = tie || adj;
+            for (int o = 1; o < kTileNR; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+            const unsigned long long fits = __ballot(rr < nrows && inc <= (unsigned)TileCap<T>::refs);
+            int ng = fits ? __ffsll((long long)~fits) - 1 : 0;        // leading run of rows that fit (rows are in lane order)
+            if (ng > nrows - r0) ng = nrows - r0;
+            if (ng == 0) {
+                // one row alone exceeds the slice: its cells are gathered from global memory by the lanes that need it
+                const int cy = Y0 + r0 % ny, cz = Z0 + r0 / ny;
+                if (cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1) {
+                    const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
+                    scan_range<T, K>(a.ref, a.cell_start[lo], a.cell_start[lo + (x1 - x0 + 1)], q, bd, bi, tie);
+                }
+                r0 += 1;
+                continue;
+            }
+            if (lane < ng) s_rowbase[lane] = inc - cnt;
+            const unsigned total = __shfl(inc, ng - 1, 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // coalesced copy: flat index -> (row, offset) by a short search in the row bases
+            for (unsigned idx = lane; idx < total; idx += 64) {
+                int lo = 0, hi = ng;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= idx) lo = mid; else hi = mid; }
+                s_ref[idx] = a.ref[s_cs[r0 + lo][0] + (idx - s_rowbase[lo])];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // each lane: its rows inside this group
+            for (int cz = z0; cz <= z1; ++cz)
+                for (int cy = y0; cy <= y1; ++cy) {
+                    const int r = (cz - Z0) * ny + (cy - Y0);
+                    if (r < r0 || r >= r0 + ng) continue;
+                    const unsigned b0 = s_cs[r][0];
+                    const bool odd = grid_row(Gy, cy, cz) & 1;       // odd rows run in -x: the table is mirrored
+                    const int i0 = odd ? X1 - x1 : x0 - X0, i1 = odd ? X1 - x0 + 1 : x1 + 1 - X0;
+                    const unsigned s = s_rowbase[r - r0] + (s_cs[r][i0] - b0), e = s_rowbase[r - r0] + (s_cs[r][i1] - b0);
+                    scan_range<T, K>(s_ref, s, e, q, bd, bi, tie);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            r0 += ng;
+        }
     }
-    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
-    wave_append(certified && tie, qpos, a.ties, a.n_ties);
+    finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, valid);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -245,8 +406,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
         for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
         for (int r = lane; r < nrows; r += 64) {
             const int cz = z0 + r / ny, cy = y0 + r % ny;
-            const int row = (cz * Gy + cy) * Gx;
-            const unsigned s = a.cell_start[row + x0], e = a.cell_start[row + x1 + 1];
+            const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
+            const unsigned s = a.cell_start[lo], e = a.cell_start[lo + (x1 - x0 + 1)];
             for (unsigned p = s; p < e; ++p) {
                 const Pt4<T> c = a.ref[p];
                 const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
