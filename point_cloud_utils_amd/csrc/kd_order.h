@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
         }
     }
     __syncthreads();
-    const size_t o = (size_t)q.idx * (size_t)k;
+    const size_t o = (size_t)a.qlist[t] * (size_t)k;                    // cell-ordered result rows
     for (int j = lane; j < k; j += 64) {                                // src/point_cloud_distance.cpp:82-93
         if (j < count) { a.out_i[o + j] = ri[j]; a.out_d[o + j] = a.squared ? rd[j] : sqrt(rd[j]); }
         else { a.out_i[o + j] = -1; a.out_d[o + j] = (T)-1; }

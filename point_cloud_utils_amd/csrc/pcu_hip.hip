@@ -495,6 +495,16 @@ struct ResultBlock {
 };
 static_assert(sizeof(ResultBlock) == 256, "ResultBlock layout");
 
+// Row-order restore of a job's cell-ordered results (either destination may be null).
+template <typename T>
+static int unpermute_enqueue(hipStream_t s, const SearchJob<T>& j, T* dst_d, long long* dst_i) {
+    const long long n_elems = (long long)j.qidx.n * j.k;
+    hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((n_elems + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       j.qidx.cell_of, j.qidx.rank, j.qidx.cell_start, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ validation
 static int validate_sizes(int64_t nq, int64_t nr, const char* qname, const char* rname) {
     if (nq <= 0 || nr <= 0)
@@ -536,7 +546,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     if (st) memset(st, 0, sizeof *st);
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k);
     const double occ_q = 2.0;
-    size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192;
+    size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
+                  align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);     // cell-ordered results
     if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + align_up((size_t)nr * 3 * sizeof(T), 256) +
                          align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);
     if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
@@ -555,7 +566,9 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         ResultBlock* rb = nullptr;
         if ((rc = aalloc(ar, &rb, 1))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
-        job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared; job.out_d = dd; job.out_i = di;
+        job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared;
+        if ((rc = aalloc(ar, &job.out_d, (size_t)nq * k))) break;
+        if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
         if ((rc = index_build(job.ridx, dr, occ, s))) break;
@@ -563,11 +576,13 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st))) break;
+        if ((rc = unpermute_enqueue(s, job, dd, di))) break;          // optimistic: redone below if stragglers / ties remain
+        tm.mark(2);
         HIP_TRY(hipMemcpyAsync(c->h_pinned, rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
+        if (rc == 1) { if ((rc = unpermute_enqueue(s, job, dd, di))) break; tm.mark(2); }
         rc = 0;
-        tm.mark(2);
         if (!on_dev) {
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
@@ -598,7 +613,8 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
                align_up((size_t)nx * sizeof(T), 256) + align_up((size_t)ny * sizeof(T), 256) +
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
                6 * align_up((size_t)kRedBlocks * 8, 256) + 8192;
-    if (!on_dev) b += align_up((size_t)nx * 3 * sizeof(T), 256) + align_up((size_t)ny * 3 * sizeof(T), 256);
+    if (!on_dev) b += align_up((size_t)nx * 3 * sizeof(T), 256) + align_up((size_t)ny * 3 * sizeof(T), 256) +
+                      align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256);
     return b;
 }
 template <typename T>
@@ -617,9 +633,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (aalloc(ar, &P.rb, 1)) return -1;
     if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
     if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
-    P.xy.out_i = ext_cxy; P.yx.out_i = ext_cyx;
-    if (!P.xy.out_i && aalloc(ar, &P.xy.out_i, (size_t)nx)) return -1;
-    if (!P.yx.out_i && aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
+    (void)ext_cxy; (void)ext_cyx;
+    if (aalloc(ar, &P.xy.out_i, (size_t)nx) || aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
     tm.mark(0);
@@ -657,7 +672,7 @@ template <typename T>
 static int argmax_enqueue(hipStream_t s, const SearchJob<T>& j, PairState<T>& P, int slot) {
     const int n = j.qidx.n;
     const int nb = std::min((n + kBlock - 1) / kBlock, kRedBlocks);
-    hipLaunchKernelGGL(k_argmax_partial<T>, dim3(nb), dim3(kBlock), 0, s, j.out_d, n, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks);
+    hipLaunchKernelGGL(k_argmax_partial<T>, dim3(nb), dim3(kBlock), 0, s, j.out_d, j.qidx.sorted, n, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks);
     hipLaunchKernelGGL(k_argmax_final<T>, dim3(1), dim3(kBlock), 0, s, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks, nb, j.out_i,
                        P.res_v + slot, P.res_ij + 2 * slot);
     HIP_TRY(hipGetLastError());
@@ -752,16 +767,22 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         const bool tie_any = !(flags & PCU_HIP_NO_TIE_ORDER);
         const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
         if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, max_leaf, tie_xy, tie_yx))) break;
+        // row-ordered correspondences: straight into the caller's device arrays, or via a staging buffer
+        long long *dst_xy = ext_xy, *dst_yx = ext_yx;
+        if (!on_dev && out_cxy && (rc = aalloc(ar, &dst_xy, (size_t)nx))) break;
+        if (!on_dev && out_cyx && (rc = aalloc(ar, &dst_yx, (size_t)ny))) break;
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
         const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);
         ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.dx, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, pc, p_norm, P.pd);
+            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, pc, p_norm, P.pd);
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nbx, P.res_s + 0);
-            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nby), dim3(kBlock), 0, s, P.dy, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, pc, p_norm, P.pd + kRedBlocks);
+            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nby), dim3(kBlock), 0, s, P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, pc, p_norm, P.pd + kRedBlocks);
             hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd + kRedBlocks, nby, P.res_s + 1);
             HIP_TRY(hipGetLastError());
+            if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
+            if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
             tm.mark(3);
             if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host); if (rc <= 0) break; rc = 0; }
             else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
@@ -769,8 +790,8 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         if (rc) break;
         const double* hs = host.sums;
         if (!on_dev) {
-            if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.xy.out_i, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
-            if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.yx.out_i, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+            if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, dst_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+            if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, dst_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
         out_mean2[0] = hs[0] / (double)nx;

@@ -17,11 +17,14 @@ __device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long lo
     if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
-// d[n]: nearest-neighbour distance per source row (already sqrt'ed unless squared was requested).
+// d[pos]: nearest-neighbour distance of the source point qsorted[pos] (cell order; already sqrt'ed unless squared was
+// requested). The key packs (original row << 32 | pos): ordering by key is ordering by original row, which is the
+// arg-max tie rule; pos is carried along to fetch the neighbour index afterwards.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_argmax_partial(const T* __restrict__ d, int n, T* pv, long long* pi) {
+__global__ __launch_bounds__(kBlock) void k_argmax_partial(const T* __restrict__ d, const Pt4<T>* __restrict__ qsorted, int n, T* pv, long long* pi) {
     T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) argmax_combine(v, idx, d[i], (long long)i);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        argmax_combine(v, idx, d[i], ((long long)qsorted[i].idx << 32) | (long long)i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_argmax_partial(const T* __restrict__
     }
 }
 
-// out3 = {bits of max value (as T in the first sizeof(T) bytes), i, j}
+// out_v = max value; out_ij = {source row i, its nearest target row j}
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_argmax_final(const T* __restrict__ pv, const long long* __restrict__ pi, int nb,
                                                          const long long* __restrict__ corr, T* out_v, long long* out_ij) {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_argmax_final(const T* __restrict__ p
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);
-        *out_v = v; out_ij[0] = idx; out_ij[1] = corr[idx];
+        *out_v = v; out_ij[0] = idx >> 32; out_ij[1] = corr[idx & 0xffffffffll];
     }
 }
 
@@ -70,25 +73,25 @@ __device__ __forceinline__ double block_sum(double s) {
 // p-norm codes (numpy.linalg.norm vector ord): 2, 1, +inf, -inf, 0, other
 enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
 
-// partial[b] = sum over the block's queries of || tgt[corr[i]] - src[i] ||_p  (fp64 accumulation).
-// For p == 2 with `d` given (non-squared nn distances) the already computed distances are summed instead:
-// they are the same numbers, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) (numpy's norm(ord=2, axis=-1) squares,
-// add-reduces in axis order and takes sqrt, in the input dtype).
+// partial[b] = sum over the block's queries of || tgt[corr[pos]] - qsorted[pos] ||_p  (fp64 accumulation; queries
+// in cell order). For p == 2 the already computed (non-squared) nn distances d[pos] are summed instead: they are
+// the same numbers, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) (numpy's norm(ord=2, axis=-1) squares, add-reduces in axis
+// order and takes sqrt, in the input dtype).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pnorm_partial(const T* __restrict__ src, const T* __restrict__ tgt,
+__global__ __launch_bounds__(kBlock) void k_pnorm_partial(const Pt4<T>* __restrict__ qsorted, const T* __restrict__ tgt,
                                                           const long long* __restrict__ corr, const T* __restrict__ d,
                                                           int n, int pcode, double p, double* partial) {
     double s = 0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         T v;
-        if (pcode == P_TWO && d) {
+        if (pcode == P_TWO) {
             v = d[i];
         } else {
             const long long c = corr[i];
-            const T a = tgt[3 * c] - src[3 * (size_t)i], b = tgt[3 * c + 1] - src[3 * (size_t)i + 1], e = tgt[3 * c + 2] - src[3 * (size_t)i + 2];
+            const Pt4<T> q = qsorted[i];
+            const T a = tgt[3 * c] - q.x, b = tgt[3 * c + 1] - q.y, e = tgt[3 * c + 2] - q.z;
             const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
-            if (pcode == P_TWO) v = sqrt(((a * a) + (b * b)) + (e * e));
-            else if (pcode == P_ONE) v = (aa + ab) + ae;
+            if (pcode == P_ONE) v = (aa + ab) + ae;
             else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; }
             else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; }
             else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));

@@ -42,8 +42,8 @@ struct SearchArgs {
     int R;                          // search radius in cells
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
-    T* out_d;                       // (nq_total, kreq), original query order
-    long long* out_i;               // (nq_total, kreq)
+    T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
+    long long* out_i;               // (nq_total, kreq)  (k_unpermute restores the caller's row order when needed)
     int* unresolved; int* n_unresolved;
     int* ties;       int* n_ties;         // MODE_FAST: possible tie; MODE_LEX: genuine tie ("true_ties")
 };
@@ -165,7 +165,7 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
     const bool certified = valid && kth < lb;
 
     if (certified) {
-        const size_t o = (size_t)q.idx * (size_t)kreq;
+        const size_t o = (size_t)qpos * (size_t)kreq;       // results stay in cell order (coalesced rows); see k_unpermute
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             if (i < kreq) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
         const bool certified = kth < lb;
         if (certified) {
             if (lane < kreq) {
-                const size_t o = (size_t)q.idx * (size_t)kreq + lane;
+                const size_t o = (size_t)qpos * (size_t)kreq + lane;
                 const bool found = my_i != 0x7fffffff;
                 a.out_i[o] = found ? (long long)my_i : -1ll;
                 a.out_d[o] = found ? (a.squared ? my_d : sqrt(my_d)) : (T)-1;
@@ -460,6 +460,24 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
             a.unresolved[atomicAdd(a.n_unresolved, 1)] = qpos;
         }
     }
+}
+
+// Restores the caller's row order: out[i, :] = res[pos(i), :], pos(i) = cell_start[cell_of[i]] + rank[i] (the slot
+// the index build gave row i). One thread per output element: reads of cell_of/rank and writes of out are
+// coalesced; the cell-ordered result rows are gathered (they were just written and are L2/MALL resident). The main
+// pass therefore writes full coalesced rows instead of scattering 4/8-byte values over the row-ordered arrays
+// (which cost ~5x the algorithmic write traffic, profiles/r01_pmc.txt).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict__ cell_of, const unsigned* __restrict__ rank,
+                                                      const unsigned* __restrict__ cell_start, const T* __restrict__ res_d,
+                                                      const long long* __restrict__ res_i, T* __restrict__ out_d,
+                                                      long long* __restrict__ out_i, long long n_elems, int k) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_elems) return;
+    const long long i = t / k; const int j = (int)(t - i * k);
+    const size_t src = (size_t)(cell_start[cell_of[i]] + rank[i]) * (size_t)k + j;
+    if (out_d) out_d[t] = res_d[src];
+    if (out_i) out_i[t] = res_i[src];
 }
 
 }  // namespace pcu
