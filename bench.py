@@ -10,7 +10,7 @@ ranks with no data-path collective (weak scaling); the per-step scalars are gath
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task description): metric/value = whole-job query-points/s,
-plus `roofline` (dominant kernel k_search<float,1,FAST>: algorithmic bytes per launch / HIP-event launch time
+plus `roofline` (dominant kernel k_search<float,1>: algorithmic bytes per launch / HIP-event launch time
 vs the 8 TB/s HBM peak) and `cpu_baseline` (the reference's nanoflann path timed on this box's host cores).
 """
 import argparse
@@ -108,7 +108,7 @@ def main():
         steps = max(args.steps, 1)
         qpts_per_step = 2 * n * world
         value = qpts_per_step * steps / dt
-        # dominant kernel: k_search<float,1,FAST>, one launch per direction = n queries vs n dataset points.
+        # dominant kernel: k_search<float,1>, one launch per direction = n queries vs n dataset points.
         # algorithmic bytes of one launch (B_knn with k=1, s=4): 3*4*n + 3*4*n + n*(4+8) = 36 B/query
         alg_bytes = 36.0 * n
         avg_ms = k_ms / max(k_n, 1)
@@ -127,7 +127,7 @@ def main():
             "config": {"workload": f"chamfer_distance, {n}-vs-{n} fp32 U[0,1)^3 clouds, one independent pair per GPU per step, "
                                    "inputs resident in HBM, scalar results gathered once (RCCL all_gather)",
                        "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_search<float,1,FAST>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_search<float,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n},
             "device_ms_per_step": {"index_build": idx_ms / steps, "search_kernels": k_ms / steps, "total": tot_ms / steps},
