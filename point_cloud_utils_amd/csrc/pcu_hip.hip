@@ -187,7 +187,9 @@ static double default_occupancy(int k) {
     return std::max(2.0, (k + 3.0 * sqrt((double)k)) / 3.7);
 }
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
-constexpr int kMaxK = 64;           // lane-per-query slots; the wave kernel uses up to 128 (k+1 rounded up)
+constexpr int kMaxKLane = 64;       // lane-per-query register slots
+constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
+constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
 constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
 template <typename T>
@@ -212,7 +214,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
 }
 template <typename T>
 static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s) {
-    dim3 grid(kWaveBlocks), block(kBlock);
+    // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
+    const int blocks = a.qcount_dev ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
+    dim3 grid(blocks), block(kBlock);
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
         PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
@@ -272,18 +276,30 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
     const SearchScratch<T>& sc = j.sc;
     const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
     HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
-    SearchArgs<T> a = base_args(j, j.ridx);
-    a.nq = j.qidx.n; a.R = 1;
-    a.unresolved = sc.u1; a.n_unresolved = sc.counters + C_U1; a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
-    const bool time_it = st && c->n_kev + 2 <= 8;
-    if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
-    if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
-    if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
     SearchArgs<T> b = base_args(j, j.ridx);
-    b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;                 // possible ties -> total order
-    b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2; b.ties = sc.tt; b.n_ties = sc.counters + C_TT;
-    if (launch_search_wave<T>(KL, b, s)) return -1;
+    b.ties = sc.tt; b.n_ties = sc.counters + C_TT;
+    // Wave-per-query from the start when lane-per-query would leave the GPU empty (few queries: a 2,885-vertex mesh
+    // against 1M samples is 46 waves of long serial scans) or when k exceeds the register top-k of the lane kernel.
+    const bool wave_only = j.k > kMaxKLane || j.qidx.n < kWaveOnlyBelow;
+    if (!wave_only) {
+        SearchArgs<T> a = base_args(j, j.ridx);
+        a.nq = j.qidx.n; a.R = 1;
+        a.unresolved = sc.u1; a.n_unresolved = sc.counters + C_U1; a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
+        const bool time_it = st && c->n_kev + 2 <= 8;
+        if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
+        if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
+        if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+        b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order
+        b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
+        if (launch_search_wave<T>(KL, b, s)) return -1;
+    } else {
+        b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
+        b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
+        if (launch_search_wave<T>(KL, b, s)) return -1;
+        b.nq = 0;
+    }
     b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;                 // stragglers, radius 2
+    b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
     if (launch_search_wave<T>(KL, b, s)) return -1;
     b.qlist = sc.u2; b.qcount_dev = sc.counters + C_U2; b.R = 4;                 // radius 4
     b.unresolved = sc.u3; b.n_unresolved = sc.counters + C_U3;

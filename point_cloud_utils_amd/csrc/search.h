@@ -426,7 +426,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
             }
         }
         // K rounds: global lexicographic minimum of the lanes' heads; the owner pops.
-        T my_d = Limits<T>::max_v; int my_i = 0x7fffffff;    // lane j keeps rank j
+        T my_d = Limits<T>::max_v; int my_i = 0x7fffffff;    // lane j keeps rank j ...
+        T my_d2 = Limits<T>::max_v; int my_i2 = 0x7fffffff;  // ... and rank j + 64 (K = 128)
         T prev_d = (T)-1; T kth = Limits<T>::max_v; bool tie = false;
 #pragma unroll 1
         for (int j = 0; j < K; ++j) {
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
                 for (int i = 0; i < K - 1; ++i) { bd[i] = bd[i + 1]; bi[i] = bi[i + 1]; }
                 bd[K - 1] = Limits<T>::max_v; bi[K - 1] = 0x7fffffff;
             }
-            if (lane == j) { my_d = md; my_i = mi; }
+            if (lane == (j & 63)) { if (j < 64) { my_d = md; my_i = mi; } else { my_d2 = md; my_i2 = mi; } }
             if (j <= kreq && mi != 0x7fffffff && md == prev_d) tie = true;
             if (j == kreq - 1) kth = md;
             prev_d = md;
@@ -454,6 +455,12 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
                 const bool found = my_i != 0x7fffffff;
                 a.out_i[o] = found ? (long long)my_i : -1ll;
                 a.out_d[o] = found ? (a.squared ? my_d : sqrt(my_d)) : (T)-1;
+            }
+            if (K > 64 && lane + 64 < kreq) {
+                const size_t o = (size_t)qpos * (size_t)kreq + lane + 64;
+                const bool found = my_i2 != 0x7fffffff;
+                a.out_i[o] = found ? (long long)my_i2 : -1ll;
+                a.out_d[o] = found ? (a.squared ? my_d2 : sqrt(my_d2)) : (T)-1;
             }
             if (tie && lane == 0) a.ties[atomicAdd(a.n_ties, 1)] = qpos;
         } else if (lane == 0) {

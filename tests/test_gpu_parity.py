@@ -62,7 +62,8 @@ def test_golden_metrics(pcu):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,m,k", [(100000, 100000, 1), (50000, 120000, 16), (30000, 30000, 5), (1000, 500, 3),
-                                   (70000, 900, 2), (900, 70000, 1), (20000, 20000, 33), (5000, 5000, 64)])
+                                   (70000, 900, 2), (900, 70000, 1), (20000, 20000, 33), (5000, 5000, 64),
+                                   (20000, 30000, 100), (3000, 4000, 127), (40000, 200, 70)])
 def test_seeded_vs_oracle(pcu, oracle_kind, dtype, n, m, k):
     q, r = cloud(1000, n, dtype), cloud(1001, m, dtype)
     d, c = pcu.k_nearest_neighbors(q, r, k)
@@ -289,3 +290,8 @@ def test_metrics_under_exact_ties(pcu, oracle_kind, dtype):
     for p in (1, np.inf, 0.5):
         v, v0 = pcu.chamfer_distance(x, y, p_norm=p), oracle.chamfer_distance(x, y, p_norm=p, kind=oracle_kind)
         assert abs(float(v) - float(v0)) <= tol * float(v0), p
+
+
+def test_k_limit_is_a_clear_error(pcu):
+    with pytest.raises(ValueError, match="k = 128 > 127"):
+        pcu.k_nearest_neighbors(cloud(1, 100, np.float32), cloud(2, 300, np.float32), 128)
