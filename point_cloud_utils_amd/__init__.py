@@ -96,7 +96,9 @@ class _Dev:
             self.a, self.b = a.contiguous(), b.contiguous()
             self.device = a.device.index if a.device.index is not None else torch.cuda.current_device()
             self.tdev = a.device
-            self.stream = torch.cuda.current_stream(a.device).cuda_stream
+            # the library call is ordered after work queued on torch's current stream, unless this thread asked for its
+            # context's private stream (batched workers; they synchronise with the producer themselves)
+            self.stream = None if _lib.use_private_stream() else torch.cuda.current_stream(a.device).cuda_stream
             self.flags = _lib.PTRS_ON_DEVICE | _ENV_FLAGS
             self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
             self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64

@@ -93,18 +93,33 @@ def default_device():
     return int(os.environ.get("PCU_HIP_DEVICE", "0"))
 
 
+_tls = threading.local()
+
+
+def private_streams(on=True):
+    """Worker threads of a batch (point_cloud_utils_amd.batched) call this: their calls then run on their own
+    context's stream instead of torch's current stream, so independent pairs overlap on the GPU."""
+    _tls.private = bool(on)
+
+
+def use_private_stream():
+    return getattr(_tls, "private", False)
+
+
 def ctx(device=None):
-    """Per-device context (stream + grow-only workspace), created on first use."""
+    """Per-(device, thread) context (stream + grow-only workspace), created on first use. A context is not
+    thread-safe; giving every Python thread its own lets independent calls from a thread pool overlap."""
     if device is None:
         device = default_device()
+    device = (int(device), threading.get_ident())
     with _lock:
         c = _ctxs.get(device)
         if c is None:
             L = lib()
             h = ctypes.c_void_p()
-            rc = L.pcu_hip_ctx_create(int(device), ctypes.byref(h))
+            rc = L.pcu_hip_ctx_create(int(device[0]), ctypes.byref(h))
             if rc != 0:
-                raise RuntimeError(f"point_cloud_utils_amd: cannot create a GPU context on device {device}: "
+                raise RuntimeError(f"point_cloud_utils_amd: cannot create a GPU context on device {device[0]}: "
                                    f"{last_error()} (this package has no CPU fallback)")
             c = h
             _ctxs[device] = c
@@ -124,5 +139,11 @@ def check(rc):
     raise RuntimeError(f"libpcu_hip: {msg}")
 
 
+class _NoLock:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 def lock():
-    return _lock
+    """Contexts are per thread, so calls need no global lock (ctypes releases the GIL during the call)."""
+    return _NoLock()

@@ -32,9 +32,14 @@ if "3" in which:
 if "4" in which:
     npairs = 8
     pairs = [(torch.from_numpy(cloud(1000 + 2 * p, 262144, np.float32)).cuda(), torch.from_numpy(cloud(1001 + 2 * p, 262144, np.float32)).cuda()) for p in range(npairs)]
+    from point_cloud_utils_amd import batched
     def run():
         return [pcu.hausdorff_distance(x, y, return_index=True) for x, y in pairs]
     t = timeit(run); res = run()
+    for w in (2, 4, 8):
+        tb = timeit(lambda: batched.batched_hausdorff(lambda p: pairs[p], npairs, workers=w))
+        rb = batched.batched_hausdorff(lambda p: pairs[p], npairs, workers=w)
+        print("   batched workers=%d: %.3f ms total (%.3g q-pts/s) same=%s" % (w, tb * 1e3, npairs * 2 * 262144 / tb, all(tuple(rb[p]) == res[p] for p in range(npairs))), flush=True)
     ok = True
     for p in range(2):
         h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
