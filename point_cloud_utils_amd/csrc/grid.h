@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ p
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T* __restrict__ partial, int nparts,
-                                                      int n, double occupancy, int max_cells) {
+                                                      int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    if (sentinel) { sentinel->x = sentinel->y = sentinel->z = (T)INFINITY; sentinel->idx = 0x7fffffff; }   // record n: see k_search
     double ext[3];
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];

@@ -147,7 +147,7 @@ static int max_cells_for(int64_t n, double occ) {
 template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
-    return align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1) * 4, 256) + align_up((size_t)n * sizeof(Pt4<T>), 256) +
+    return align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1) * 4, 256) + align_up((size_t)(n + 1) * sizeof(Pt4<T>), 256) +
            2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
 }
 template <typename T>
@@ -155,7 +155,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ) {
     g.n = (int)n; g.max_cells = max_cells_for(n, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
     if (aalloc(a, &g.gp, 1)) return -1;
     if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1)) return -1;
-    if (aalloc(a, &g.sorted, (size_t)n)) return -1;
+    if (aalloc(a, &g.sorted, (size_t)n + 1)) return -1;        // + the +inf sentinel record
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
@@ -168,7 +168,7 @@ static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t 
     const int n = g.n;
     const int nb = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.max_cells + 1);
-    hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells);
+    hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells, g.sorted + n);
     hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
     hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
     hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
@@ -262,7 +262,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
 template <typename T>
 static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) {
     SearchArgs<T> a;
-    a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted;
+    a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted; a.n_ref = (unsigned)ridx.n;
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
@@ -527,8 +527,8 @@ static int validate_sizes(int64_t nq, int64_t nr, const char* qname, const char*
         return fail(PCU_HIP_ERR_INVALID,
                     "Invalid input set with zero elements: %s and %s must have shape (n, 3) and (m, 3). "
                     "Got %s.shape = (%lld, 3), %s.shape = (%lld, 3).", qname, rname, qname, (long long)nq, rname, (long long)nr);
-    if (nq > 0x7ffffff0ll || nr > 0x7ffffff0ll)
-        return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^31-16 rows are not supported");
+    if (nq > 0x07fffff0ll || nr > 0x07fffff0ll)      // record byte offsets are 32-bit (32-byte f64 records)
+        return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^27-16 rows are not supported");
     return 0;
 }
 

@@ -40,6 +40,7 @@ struct SearchArgs {
     const int* qcount_dev;          // nullable: device-side count for qlist passes
     int nq;                         // number of work items when qcount_dev is null
     int R;                          // search radius in cells
+    unsigned n_ref;                 // number of dataset records; ref[n_ref] is the +inf sentinel record
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
     T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
@@ -228,13 +229,24 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
         const unsigned e = a.cell_start[lo + (x1 - x0 + 1)];
         re[j] = ok ? e : rs[j];
     }
+    // Candidates are consumed kGroup at a time. Slots past the end of a row read the sentinel record sorted[n]
+    // (all coordinates +inf -> d2 = +inf, never < nor == anything), so a group is straight-line code with no
+    // per-slot masking, and record addresses are 32-bit byte offsets from a uniform base (one shift per load).
+    constexpr int kGroup = 4;
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const unsigned sentinel = a.n_ref;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const unsigned e = re[j];
-        for (unsigned p = rs[j]; p < e; p += 4) {
-            const unsigned last = e - 1;
-            const Pt4<T> c0 = a.ref[p], c1 = a.ref[min(p + 1, last)], c2 = a.ref[min(p + 2, last)], c3 = a.ref[min(p + 3, last)];
-            offer4<T, K>(q, c0, c1, c2, c3, p, e, bd, bi, tie);
+        for (unsigned p = rs[j]; p < e; p += kGroup) {
+            Pt4<T> c[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const unsigned idx = (p + u < e) ? p + u : sentinel;
+                c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) offer<T, K>(dist2(q, c[u]), (int)c[u].idx, bd, bi, tie);
         }
     }
 
