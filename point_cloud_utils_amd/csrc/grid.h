@@ -133,6 +133,8 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
         gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
     }
     gp->ncells = G[0] * G[1] * G[2];
+    for (int j = 0; j < 3; ++j) gp->org[j] = gp->gmin[j];
+    gp->sumsq = 0ull;
 }
 
 template <typename T>
@@ -142,12 +144,21 @@ __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const T x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-    const int cx = cell_coord(x, gp->gmin[0], gp->inv_h, gp->G[0]);
-    const int cy = cell_coord(y, gp->gmin[1], gp->inv_h, gp->G[1]);
-    const int cz = cell_coord(z, gp->gmin[2], gp->inv_h, gp->G[2]);
+    const int cx = grid_cell(*gp, 0, x), cy = grid_cell(*gp, 1, y), cz = grid_cell(*gp, 2, z);
     const unsigned c = (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], cy, cz), cx, cx);
     cell_of[i] = c;
-    rank[i] = atomicAdd(&counts[c], 1u);
+    // A wave whose lanes all fall into one cell (degenerate grids: a far outlier inflating the bbox, duplicated
+    // points) issues ONE atomic instead of 64 on the same address.
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)act) - 1;
+    if (__all(c == (unsigned)__shfl((int)c, first, 64))) {
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(&counts[c], (unsigned)__popcll(act));
+        base = (unsigned)__shfl((int)base, first, 64);
+        rank[i] = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
+    } else {
+        rank[i] = atomicAdd(&counts[c], 1u);
+    }
 }
 
 // ---- exclusive scan over `counts[0..m)` in place; counts[m] receives the total -------------------------
@@ -176,15 +187,21 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* t
 
 // m is read from device memory (gp->ncells) so no host round trip is needed between build stages.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ counts, const GridParams<T>* __restrict__ gp,
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ counts, GridParams<T>* gp,
                                                         unsigned* __restrict__ block_sums) {
     const int m = gp->ncells;
     const int base = blockIdx.x * kScanChunk;
     if (base >= m) { if (threadIdx.x == 0) block_sums[blockIdx.x] = 0; return; }
-    unsigned s = 0;
+    unsigned s = 0; unsigned long long s2 = 0;       // s2: balance metric sum(count^2), see GridParams::sumsq
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) { int i = base + j * kBlock + threadIdx.x; if (i < m) s += counts[i]; }
+    for (int j = 0; j < kScanItems; ++j) {
+        int i = base + j * kBlock + threadIdx.x;
+        if (i < m) { const unsigned c = counts[i]; s += c; s2 += (unsigned long long)c * c; }
+    }
     unsigned total; block_exclusive_scan(s, &total);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    if ((threadIdx.x & 63) == 0 && s2) atomicAdd(&gp->sumsq, s2);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -220,6 +237,108 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
     Pt4<T> p;
     p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; p.idx = i;
     sorted[cell_start[cell_of[i]] + rank[i]] = p;
+}
+
+// ---- refitting the grid of an unbalanced cloud -----------------------------------------------------------------------
+// When the first (bbox-filling, mean-density) grid turns out badly unbalanced -- clusters, blobs, a far outlier that
+// inflates the bbox -- finer grids are fitted to the *core* of the cloud: three rounds of per-axis 1024-bin
+// histograms, each over the range that held all but ~2/4096 of the mass in the previous round (1024^3 dynamic
+// range), give the core range; k_make_grid_refit lays `target_cells` cubic cells over it. Points outside the core
+// fall into the border cells. The grid only decides which candidates are looked at, never the result.
+constexpr int kHistBins = 1024;            // + underflow bin 0 and overflow bin kHistBins + 1
+constexpr int kHistBlocks = 128;
+
+template <typename T>
+struct QuantState { T lo[3], hi[3]; };     // histogram range of the current round
+
+template <typename T>
+__global__ void k_quant_init(const GridParams<T>* gp, QuantState<T>* qs) {
+    if (threadIdx.x < 3) { qs->lo[threadIdx.x] = gp->gmin[threadIdx.x]; qs->hi[threadIdx.x] = gp->gmax[threadIdx.x]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_hist_axis(const T* __restrict__ pts, int n, const QuantState<T>* __restrict__ qs,
+                                                      unsigned* __restrict__ partial) {
+    __shared__ unsigned h[3][kHistBins + 2];
+    for (int i = threadIdx.x; i < 3 * (kHistBins + 2); i += kBlock) (&h[0][0])[i] = 0;
+    __syncthreads();
+    T lo[3], sc[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = qs->lo[a]; const T w = qs->hi[a] - qs->lo[a]; sc[a] = w > 0 ? (T)kHistBins / w : (T)0; }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const T t = (pts[3 * (size_t)i + a] - lo[a]) * sc[a];
+            const int b = (t >= 0) ? ((t < (T)kHistBins) ? 1 + (int)t : kHistBins + 1) : 0;
+            atomicAdd(&h[a][b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * (kHistBins + 2); i += kBlock) partial[(size_t)blockIdx.x * 3 * (kHistBins + 2) + i] = (&h[0][0])[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_hist_merge(const unsigned* __restrict__ partial, int nblocks, unsigned* __restrict__ hist) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 3 * (kHistBins + 2)) return;
+    unsigned s = 0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 3 * (kHistBins + 2) + i];
+    hist[i] = s;
+}
+
+// Per axis (3 threads): zoom the range to the bins that hold all but n/4096 of the mass at either end.
+template <typename T>
+__global__ void k_quant_zoom(QuantState<T>* qs, const unsigned* __restrict__ hist, int n) {
+    const int a = threadIdx.x;
+    if (a >= 3) return;
+    const unsigned* h = hist + a * (kHistBins + 2);
+    const T lo = qs->lo[a], hi = qs->hi[a];
+    const double w = ((double)hi - (double)lo) / kHistBins;
+    if (!(w > 0)) return;
+    const double tail = (double)n / 4096.0;
+    double c = h[0]; int b0 = 0;
+    while (b0 < kHistBins - 1 && c + h[1 + b0] <= tail) { c += h[1 + b0]; ++b0; }
+    c = h[kHistBins + 1]; int b1 = kHistBins - 1;
+    while (b1 > b0 && c + h[1 + b1] <= tail) { c += h[1 + b1]; --b1; }
+    qs->lo[a] = (T)((double)lo + b0 * w); qs->hi[a] = (T)((double)lo + (b1 + 1) * w);
+}
+
+// Cubic cells of about `target_cells` over the core range qs (exact bbox kept in gmin/gmax for certification).
+template <typename T>
+__global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, const QuantState<T>* qs, double target_cells,
+                                  int max_cells, Pt4<T>* sentinel) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (sentinel) { sentinel->x = sentinel->y = sentinel->z = (T)INFINITY; sentinel->idx = 0x7fffffff; }
+    double ext[3];
+    for (int j = 0; j < 3; ++j) { gp->gmin[j] = base->gmin[j]; gp->gmax[j] = base->gmax[j]; gp->org[j] = qs->lo[j]; ext[j] = (double)qs->hi[j] - (double)qs->lo[j]; }
+    double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
+    double want = target_cells;
+    if (want > (double)max_cells) want = (double)max_cells;
+    if (want < 1.0) want = 1.0;
+    int G[3] = {1, 1, 1};
+    double h = 1.0;
+    if (emax > 0 && isfinite(emax)) {
+        bool act[3]; int nd = 0; double vol = 1.0;
+        for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
+        h = pow(vol / want, 1.0 / nd);
+        for (int it = 0; it < 400; ++it) {
+            double cells = 1.0;
+            for (int j = 0; j < 3; ++j) {
+                double g = act[j] ? floor(ext[j] / h) + 1.0 : 1.0;
+                if (g > 2048.0) g = 2048.0;
+                G[j] = (int)g; cells *= g;
+            }
+            if (cells <= (double)max_cells) break;
+            h *= 1.05;
+        }
+    }
+    gp->h = (T)h;
+    gp->inv_h = (T)1 / gp->h;
+    for (int j = 0; j < 3; ++j) {
+        gp->G[j] = G[j];
+        double scale = fabs((double)gp->org[j]) + fabs((double)qs->hi[j]) + (double)G[j] * h;
+        gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
+    }
+    gp->ncells = G[0] * G[1] * G[2];
+    gp->sumsq = 0ull;
 }
 
 }  // namespace pcu

@@ -177,6 +177,39 @@ static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t 
     return 0;
 }
 
+// Refitted grids for unbalanced clouds (grid.h): core range of the cloud by three zooming histogram rounds, then
+// uniform grids of a chosen cell count over that range. Everything is enqueued on `s` (no host sync).
+template <typename T>
+static int core_range_enqueue(Arena& ar, const GridIndex<T>& base, const T* d_pts, hipStream_t s, QuantState<T>** out_qs) {
+    QuantState<T>* qs = nullptr; unsigned *partial = nullptr, *hist = nullptr;
+    if (aalloc(ar, &qs, 1) || aalloc(ar, &partial, (size_t)kHistBlocks * 3 * (kHistBins + 2)) || aalloc(ar, &hist, 3 * (kHistBins + 2))) return -1;
+    hipLaunchKernelGGL(k_quant_init<T>, dim3(1), dim3(64), 0, s, base.gp, qs);
+    for (int r = 0; r < 3; ++r) {
+        hipLaunchKernelGGL(k_hist_axis<T>, dim3(kHistBlocks), dim3(kBlock), 0, s, d_pts, base.n, qs, partial);
+        hipLaunchKernelGGL(k_hist_merge, dim3((3 * (kHistBins + 2) + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, kHistBlocks, hist);
+        hipLaunchKernelGGL(k_quant_zoom<T>, dim3(1), dim3(64), 0, s, qs, hist, base.n);
+    }
+    HIP_TRY(hipGetLastError());
+    *out_qs = qs;
+    return 0;
+}
+template <typename T>
+static int index_build_refit(Arena& ar, GridIndex<T>& g, const GridIndex<T>& base, const T* d_pts, const QuantState<T>* qs,
+                             double target_cells, hipStream_t s) {
+    const int n = base.n;
+    if (target_cells < 1.0) target_cells = 1.0;
+    if (index_alloc(ar, g, n, (double)n / target_cells)) return -1;
+    const int nb = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n);
+    HIP_TRY(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * 4, s));
+    hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
+    hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
+    hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
+    hipLaunchKernelGGL(k_scatter<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.cell_of, g.rank, g.cell_start, g.sorted);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ search driver
 static double default_occupancy(int k) {
     // Dataset points per grid cell. More points per cell = more candidates per query in the main pass but fewer
@@ -190,6 +223,7 @@ static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 constexpr int kMaxKLane = 64;       // lane-per-query register slots
 constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
 constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
+constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1)
 constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
 template <typename T>
@@ -228,20 +262,21 @@ static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s) {
 }
 
 // Per-direction lists and counters. Counter slots:
-enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_N = 8 };
+enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_SKEW = 6, C_X0 = 7, C_X1 = 8, C_N = 12 };
 template <typename T>
 struct SearchScratch {
-    int *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *t1 = nullptr, *tt = nullptr;
+    int *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *t1 = nullptr, *tt = nullptr, *x0 = nullptr, *x1 = nullptr;
     int* counters = nullptr;
     int nq = 0;
 };
 template <typename T>
-static size_t scratch_bytes(int64_t nq) { return 5 * align_up((size_t)nq * 4, 256) + 256; }
+static size_t scratch_bytes(int64_t nq) { return 7 * align_up((size_t)nq * 4, 256) + 256; }
 template <typename T>
 static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq, int* counters_ext = nullptr) {
     sc.nq = (int)nq;
     if (aalloc(a, &sc.u1, (size_t)nq) || aalloc(a, &sc.u2, (size_t)nq) || aalloc(a, &sc.u3, (size_t)nq)) return -1;
     if (aalloc(a, &sc.t1, (size_t)nq) || aalloc(a, &sc.tt, (size_t)nq)) return -1;
+    if (aalloc(a, &sc.x0, (size_t)nq) || aalloc(a, &sc.x1, (size_t)nq)) return -1;
     sc.counters = counters_ext;
     if (!sc.counters && aalloc(a, &sc.counters, C_N)) return -1;
     return 0;
@@ -255,6 +290,8 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     int k = 1; bool squared = false;
     int leaf_max = 10; bool tie_order = true;   // reference's max_points_per_leaf: defines the order of exact ties
     int n_tt = 0;                               // genuine-tie queries found (filled by search_finish)
+    bool skew_check = true;                     // give up early on a badly unbalanced dataset grid (then: refitted finer grids)
+    GridIndex<T> fine[2]; int n_fine = 0;       // finer dataset grids for the dense parts, finest first (unbalanced clouds only)
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
 };
@@ -266,6 +303,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
+    a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     return a;
 }
 
@@ -282,21 +320,33 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
     // against 1M samples is 46 waves of long serial scans) or when k exceeds the register top-k of the lane kernel.
     const bool wave_only = j.k > kMaxKLane || j.qidx.n < kWaveOnlyBelow;
     if (!wave_only) {
-        SearchArgs<T> a = base_args(j, j.ridx);
-        a.nq = j.qidx.n; a.R = 1;
-        a.unresolved = sc.u1; a.n_unresolved = sc.counters + C_U1; a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
-        const bool time_it = st && c->n_kev + 2 <= 8;
-        if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
-        if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
-        if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+        // Lane-per-query passes, finest dataset grid first: a query is served by the finest grid that certifies it
+        // (dense regions), the rest falls through to the coarser grids (sparse regions) and finally to `ridx`.
+        const int* lst = nullptr; const int* cnt = nullptr;
+        for (int lv = 0; lv <= j.n_fine; ++lv) {
+            const bool last = lv == j.n_fine;
+            SearchArgs<T> a = base_args(j, last ? j.ridx : j.fine[lv]);
+            a.qlist = lst; a.qcount_dev = cnt; a.nq = j.qidx.n; a.R = 1;
+            a.unresolved = last ? sc.u1 : (lv == 0 ? sc.x0 : sc.x1);
+            a.n_unresolved = sc.counters + (last ? C_U1 : (lv == 0 ? C_X0 : C_X1));
+            a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
+            // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
+            if (last && j.skew_check && j.n_fine == 0) a.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
+            const bool time_it = st && lv == 0 && c->n_kev + 2 <= 8;
+            if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
+            if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
+            if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+            lst = a.unresolved; cnt = a.n_unresolved;
+        }
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
         if (launch_search_wave<T>(KL, b, s)) return -1;
     } else {
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
+        if (j.skew_check) b.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
         if (launch_search_wave<T>(KL, b, s)) return -1;
-        b.nq = 0;
+        b.nq = 0; b.skew_limit = 0.f;
     }
     b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;                 // stragglers, radius 2
     b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
@@ -450,13 +500,46 @@ template <typename T>
 static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc) {
     // hc: host copy of j.sc.counters, read back by the caller together with the call's scalar results
     // (one D2H copy + one stream sync for the whole call in the common case)
+    int hc_redo[C_N];
+    bool redone = false;
+    if (hc[C_SKEW]) {
+        // The dataset grid is badly unbalanced (clusters, blobs, a far outlier inflating the bbox): every pass gave up
+        // at once. Refit: same cell count over the core range of the cloud (replaces `ridx`), then up to two finer
+        // grids sized by how unbalanced the previous one still is; the passes then run finest grid first.
+        QuantState<T>* qs = nullptr;
+        if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
+        const double n = (double)j.ridx.n, cap = 16.0 * 1024 * 1024;
+        double cells = n / j.occ;
+        GridIndex<T> lv[3]; double metric[3]; int nlv = 0;
+        for (int it = 0; it < 3; ++it) {
+            if (index_build_refit(ar, lv[nlv], j.ridx, j.d_ref_pts, qs, cells, s)) return -1;
+            GridParams<T> hp;
+            HIP_TRY(hipMemcpyAsync(&hp, lv[nlv].gp, sizeof hp, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (st) st->n_grid_builds++;
+            metric[nlv] = (double)hp.sumsq / n / (j.occ + 1.0);        // 1 = as balanced as uniform random data
+            ++nlv;
+            const double m = metric[nlv - 1];
+            if (m <= 3.0 || cells >= cap) break;
+            cells = std::min(cap, cells * std::min(64.0, it == 0 ? m : pow(m, 1.5)));
+        }
+        // lv[0] is the coarsest (becomes the base grid), lv[nlv-1] the finest; keep a finer level only if it helps
+        j.ridx = lv[0]; j.n_fine = 0;
+        for (int i = nlv - 1; i >= 1 && j.n_fine < 2; --i)
+            if (metric[i] < 0.7 * metric[i - 1]) j.fine[j.n_fine++] = lv[i];
+        j.skew_check = false;
+        if (search_enqueue(c, s, j, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        hc = hc_redo; redone = true;
+    }
     if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
     int n_left = hc[C_U3];
     if (n_left == 0) {
         if (st) st->n_tie_true += hc[C_TT];
         j.n_tt = hc[C_TT];
         if (hc[C_TT] > 0 && j.tie_order) { if (tie_order_resolve(c, ar, s, j, hc[C_TT], st)) return -1; return 1; }
-        return 0;
+        return redone ? 1 : 0;
     }
     const int KL = std::max(2, pow2_at_least(j.k + 1));
     int* cur = j.sc.u3; int* nxt = j.sc.u1;
@@ -503,11 +586,11 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
 // One 256-byte device block per call holds everything the host must read back: both directions' counters and
 // the scalar results. It is copied to pinned host memory with a single hipMemcpyAsync.
 struct ResultBlock {
-    int counters[2][C_N];        //   0..63   bytes
-    double sums[2];              //  64..79
-    double vals[2];              //  80..95   (T-typed values stored in the first sizeof(T) bytes of each slot pair)
-    long long ij[4];             //  96..127
-    int pad[32];
+    int counters[2][C_N];        //   0..95   bytes
+    double sums[2];              //  96..111
+    double vals[2];              // 112..127  (T-typed values stored in the first sizeof(T) bytes of each slot pair)
+    long long ij[4];             // 128..159
+    int pad[24];
 };
 static_assert(sizeof(ResultBlock) == 256, "ResultBlock layout");
 

@@ -49,6 +49,10 @@ struct GridParams {
     T slack[3];               // conservative slack on cell-face positions (certification, see search.h)
     int G[3];                 // cells per axis
     int ncells;               // G[0]*G[1]*G[2]
+    T org[3];                 // grid origin: = gmin, or the low corner of the core range when far outliers were
+                              // clipped (clouds refitted after an unbalanced first grid); cells at the grid border
+                              // then also hold everything beyond it
+    unsigned long long sumsq; // sum over cells of count^2 (balance metric: sumsq / n = mean number of cell mates)
 };
 
 // Cell coordinate of value v along one axis. Separate subtract and multiply (the TU is built with
@@ -58,6 +62,18 @@ __device__ __forceinline__ int cell_coord(T v, T gmin, T inv_h, int G) {
     T t = (v - gmin) * inv_h;
     return (t >= (T)0) ? ((t < (T)G) ? (int)t : G - 1) : 0;
 }
+
+template <typename T>
+__device__ __forceinline__ int grid_cell(const GridParams<T>& g, const int axis, const T v) {
+    return cell_coord(v, g.org[axis], g.inv_h, g.G[axis]);
+}
+// Every point whose cell coordinate along `axis` is <  c has a coordinate <  face_below(c)  (c >= 1);
+// every point whose cell coordinate along `axis` is >  c has a coordinate >= face_above(c)  (c <= G-2).
+// The slack covers the rounding of (v - org) * inv_h in cell_coord.
+template <typename T>
+__device__ __forceinline__ T face_below(const GridParams<T>& g, const int axis, const int c) { return g.org[axis] + (T)c * g.h + g.slack[axis]; }
+template <typename T>
+__device__ __forceinline__ T face_above(const GridParams<T>& g, const int axis, const int c) { return g.org[axis] + (T)(c + 1) * g.h - g.slack[axis]; }
 
 // Cell order: boustrophedon ("snake"). Rows (y,z) are numbered z-major with y reversed on odd z, and cells inside
 // a row run in +x on even rows and -x on odd rows, so consecutive cells of the linear order are always face

@@ -41,6 +41,8 @@ struct SearchArgs {
     int nq;                         // number of work items when qcount_dev is null
     int R;                          // search radius in cells
     unsigned n_ref;                 // number of dataset records; ref[n_ref] is the +inf sentinel record
+    float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
+    int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then builds a quantile grid
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
     T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
@@ -80,7 +82,7 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (c0[j] > 0) {              // points with cell_j <= c0-1: coordinate < gmin + c0*h (+slack)
-            T B = g.gmin[j] + (T)c0[j] * g.h + g.slack[j];
+            T B = face_below(g, j, c0[j]);
             T m = q[j] - B;
             m = m > (T)0 ? m * shrink : (T)0;
             m = m > o[j] ? m : o[j];
@@ -89,7 +91,7 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
             lb = f < lb ? f : lb;
         }
         if (c1[j] < g.G[j] - 1) {     // points with cell_j >= c1+1: coordinate >= gmin + (c1+1)*h (-slack)
-            T B = g.gmin[j] + (T)(c1[j] + 1) * g.h - g.slack[j];
+            T B = face_above(g, j, c1[j]);
             T m = B - q[j];
             m = m > (T)0 ? m * shrink : (T)0;
             m = m > o[j] ? m : o[j];
@@ -203,11 +205,10 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
 
-    const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
-    const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
-    const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
     const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
     const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
@@ -295,10 +296,9 @@ __global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
     const int qpos = valid ? t0 + lane : nq - 1;            // padding lanes mirror the last query (no effect on the box)
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
-    const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
-    const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
     const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
     const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
@@ -400,14 +400,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
     const int nwaves = (gridDim.x * kBlock) >> 6;
     const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
     const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (wave == 0 && lane == 0) *a.skew_flag = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int R = a.R, kreq = a.kreq;
     for (int w = wave; w < nq; w += nwaves) {
         const int qpos = a.qlist ? a.qlist[w] : w;
         const Pt4<T> q = a.qsorted[qpos];
-        const int ccx = cell_coord(q.x, g.gmin[0], g.inv_h, Gx);
-        const int ccy = cell_coord(q.y, g.gmin[1], g.inv_h, Gy);
-        const int ccz = cell_coord(q.z, g.gmin[2], g.inv_h, Gz);
+        const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
         const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
         const int y0 = max(ccy - R, 0), y1 = min(ccy + R, Gy - 1);
         const int z0 = max(ccz - R, 0), z1 = min(ccz + R, Gz - 1);

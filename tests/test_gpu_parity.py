@@ -295,3 +295,25 @@ def test_metrics_under_exact_ties(pcu, oracle_kind, dtype):
 def test_k_limit_is_a_clear_error(pcu):
     with pytest.raises(ValueError, match="k = 128 > 127"):
         pcu.k_nearest_neighbors(cloud(1, 100, np.float32), cloud(2, 300, np.float32), 128)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_unbalanced_clouds_refit_path(pcu, oracle_kind, dtype):
+    """A far outlier inflating the bbox and a tight cluster: the first grid is badly unbalanced, the passes give up,
+    finer grids are refitted over the core of the cloud (multi-resolution passes). Results must not change."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    r = np.concatenate([rng.random((n * 9 // 10, 3)), rng.normal(0.5, 0.002, (n // 10, 3))]).astype(dtype)
+    r[0] = [900.0, -700.0, 800.0]                       # one stray point
+    q = np.concatenate([rng.random((n // 2, 3)), rng.normal(0.5, 0.002, (n // 2, 3))]).astype(dtype)
+    q[1] = [-500.0, 500.0, 0.0]
+    for k in (1, 4):
+        d, c = pcu.k_nearest_neighbors(q, r, k)
+        st = pcu.last_stats()
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+        _assert_knn(pcu, d, c, d0, c0)
+        assert st["n_grid_builds"] > 2, st              # the refit path was taken
+    assert pcu.hausdorff_distance(q, r, return_index=True) == oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
+    ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
