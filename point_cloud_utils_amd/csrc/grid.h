@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
     }
     gp->ncells = G[0] * G[1] * G[2];
     for (int j = 0; j < 3; ++j) gp->org[j] = gp->gmin[j];
-    gp->sumsq = 0ull;
+    gp->sumsq = 0ull; gp->closed = 0;
 }
 
 template <typename T>
@@ -144,6 +144,11 @@ __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const T x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    if (gp->closed) {      // sub-box level: points outside the box are simply not part of this index
+        const T tx = (x - gp->org[0]) * gp->inv_h, ty = (y - gp->org[1]) * gp->inv_h, tz = (z - gp->org[2]) * gp->inv_h;
+        const bool in = tx >= 0 && tx < (T)gp->G[0] && ty >= 0 && ty < (T)gp->G[1] && tz >= 0 && tz < (T)gp->G[2];
+        if (!in) { cell_of[i] = 0xffffffffu; rank[i] = 0; return; }
+    }
     const int cx = grid_cell(*gp, 0, x), cy = grid_cell(*gp, 1, y), cz = grid_cell(*gp, 2, z);
     const unsigned c = (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], cy, cz), cx, cx);
     cell_of[i] = c;
@@ -225,7 +230,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* counts, const G
     unsigned ex = block_exclusive_scan(s, &total) + ptotal;
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) { if (i0 + j < m) counts[i0 + j] = ex; ex += v[j]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[m] = n_total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_total == 0xffffffffu) { n_total = 0; for (int b = 0; b * kScanChunk < m; ++b) n_total += block_sums[b]; }   // closed index: count what is in it
+        counts[m] = n_total;
+    }
 }
 
 template <typename T>
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
                                                     Pt4<T>* __restrict__ sorted) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    if (cell_of[i] == 0xffffffffu) return;            // not part of a closed (sub-box) index
     Pt4<T> p;
     p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; p.idx = i;
     sorted[cell_start[cell_of[i]] + rank[i]] = p;
@@ -304,8 +313,9 @@ __global__ void k_quant_zoom(QuantState<T>* qs, const unsigned* __restrict__ his
 // Cubic cells of about `target_cells` over the core range qs (exact bbox kept in gmin/gmax for certification).
 template <typename T>
 __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, const QuantState<T>* qs, double target_cells,
-                                  int max_cells, Pt4<T>* sentinel) {
+                                  int max_cells, Pt4<T>* sentinel, int closed, const double* target_dev) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (target_dev) target_cells = *target_dev;
     if (sentinel) { sentinel->x = sentinel->y = sentinel->z = (T)INFINITY; sentinel->idx = 0x7fffffff; }
     double ext[3];
     for (int j = 0; j < 3; ++j) { gp->gmin[j] = base->gmin[j]; gp->gmax[j] = base->gmax[j]; gp->org[j] = qs->lo[j]; ext[j] = (double)qs->hi[j] - (double)qs->lo[j]; }
@@ -338,7 +348,69 @@ __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, 
         gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
     }
     gp->ncells = G[0] * G[1] * G[2];
-    gp->sumsq = 0ull;
+    gp->sumsq = 0ull; gp->closed = closed;
+}
+
+// Heavy part of an indexed cloud: bounding box (+1 cell) and number of the points that sit in cells holding more than
+// `thresh` points, and the cell count a sub-box grid over it should get: the parent's cells inside the box times how
+// overfull the heavy cells are. Two stages: per-block partials {lo[3], hi[3], count, sum of cell counts}, one block folds.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_heavy_partial(const T* __restrict__ pts, int n, const unsigned* __restrict__ cell_of,
+                                                          const unsigned* __restrict__ cell_start, unsigned thresh,
+                                                          T* __restrict__ pbox, double* __restrict__ pcnt) {
+    T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+    double cnt = 0, sq = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned c = cell_of[i];
+        if (c == 0xffffffffu) continue;
+        const unsigned k = cell_start[c + 1] - cell_start[c];
+        if (k <= thresh) continue;
+        cnt += 1; sq += k;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const T v = pts[3 * (size_t)i + j]; lo[j] = v < lo[j] ? v : lo[j]; hi[j] = v > hi[j] ? v : hi[j]; }
+    }
+    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3]; __shared__ double s_c[kBlock / 64], s_q[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const T a = wave_min(lo[j]), b = wave_max(hi[j]); if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = b; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sq += __shfl_xor(sq, o, 64); }
+    if (lane == 0) { s_c[wave] = cnt; s_q[wave] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double C = 0, Q = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { C += s_c[w]; Q += s_q[w]; }
+        for (int j = 0; j < 3; ++j) {
+            T a = s_lo[0][j], b = s_hi[0][j];
+            for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
+            pbox[blockIdx.x * 6 + j] = a; pbox[blockIdx.x * 6 + 3 + j] = b;
+        }
+        pcnt[blockIdx.x * 2] = C; pcnt[blockIdx.x * 2 + 1] = Q;
+    }
+}
+template <typename T>
+__global__ void k_heavy_finish(const GridParams<T>* __restrict__ gp, const T* __restrict__ pbox, const double* __restrict__ pcnt, int nparts,
+                               double occ, double cap, QuantState<T>* out, double* out_target) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double C = 0, Q = 0;
+    T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+    for (int b = 0; b < nparts; ++b) {
+        C += pcnt[2 * b]; Q += pcnt[2 * b + 1];
+        for (int j = 0; j < 3; ++j) { const T a = pbox[b * 6 + j], c = pbox[b * 6 + 3 + j]; lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j]; }
+    }
+    double cells_in_box = 1;
+    for (int j = 0; j < 3; ++j) {
+        T a = lo[j], b = hi[j];
+        if (!(a <= b)) { a = 0; b = 0; }
+        out->lo[j] = a - gp->h; out->hi[j] = b + gp->h;
+        cells_in_box *= (gp->G[j] > 1) ? ((double)(b - a) / (double)gp->h + 2.0) : 1.0;
+    }
+    const double overfull = C > 0 ? (Q / C) / occ : 1.0;        // mean count of a heavy point's cell / wanted occupancy
+    double t = cells_in_box * overfull;
+    if (t < C / occ * 0.25) t = C / occ * 0.25;
+    if (t > cap) t = cap;
+    if (t < 1) t = 1;
+    *out_target = t;
 }
 
 }  // namespace pcu

@@ -195,19 +195,30 @@ static int core_range_enqueue(Arena& ar, const GridIndex<T>& base, const T* d_pt
 }
 template <typename T>
 static int index_build_refit(Arena& ar, GridIndex<T>& g, const GridIndex<T>& base, const T* d_pts, const QuantState<T>* qs,
-                             double target_cells, hipStream_t s) {
+                             double target_cells, hipStream_t s, bool closed = false, const double* target_dev = nullptr) {
+    // closed: sub-box level (only the points inside the box are indexed); target_dev: cell count decided on the device
     const int n = base.n;
     if (target_cells < 1.0) target_cells = 1.0;
     if (index_alloc(ar, g, n, (double)n / target_cells)) return -1;
     const int nb = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n);
+    hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n,
+                       closed ? 1 : 0, target_dev);
     HIP_TRY(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * 4, s));
     hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
     hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
-    hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
+    hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, closed ? 0xffffffffu : (unsigned)n);
     hipLaunchKernelGGL(k_scatter<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.cell_of, g.rank, g.cell_start, g.sorted);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+// Sub-box level over the heavy cells of `parent` (cells holding more than `thresh` points): enqueue only.
+template <typename T>
+static int index_build_heavy(Arena& ar, GridIndex<T>& g, const GridIndex<T>& parent, const T* d_pts, double occ, unsigned thresh, hipStream_t s) {
+    QuantState<T>* qs = nullptr; T* pbox = nullptr; double *pcnt = nullptr, *target = nullptr;
+    if (aalloc(ar, &qs, 1) || aalloc(ar, &pbox, (size_t)kBboxBlocks * 6) || aalloc(ar, &pcnt, (size_t)kBboxBlocks * 2) || aalloc(ar, &target, 2)) return -1;
+    hipLaunchKernelGGL(k_heavy_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, parent.n, parent.cell_of, parent.cell_start, thresh, pbox, pcnt);
+    hipLaunchKernelGGL(k_heavy_finish<T>, dim3(1), dim3(64), 0, s, parent.gp, pbox, pcnt, kBboxBlocks, occ, 16.0 * 1024 * 1024, qs, target);
+    return index_build_refit(ar, g, parent, d_pts, qs, (double)parent.n / occ, s, /*closed=*/true, target);
 }
 
 // ------------------------------------------------------------------------------------------------ search driver
@@ -223,7 +234,8 @@ static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 constexpr int kMaxKLane = 64;       // lane-per-query register slots
 constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
 constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
-constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1)
+constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
+                                        // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)
 constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
 template <typename T>
@@ -304,6 +316,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
     a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
+    a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     return a;
 }
 
@@ -508,30 +521,28 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         // grids sized by how unbalanced the previous one still is; the passes then run finest grid first.
         QuantState<T>* qs = nullptr;
         if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
-        const double n = (double)j.ridx.n, cap = 16.0 * 1024 * 1024;
-        double cells = n / j.occ;
-        GridIndex<T> lv[3]; double metric[3]; int nlv = 0;
-        for (int it = 0; it < 3; ++it) {
-            if (index_build_refit(ar, lv[nlv], j.ridx, j.d_ref_pts, qs, cells, s)) return -1;
-            GridParams<T> hp;
-            HIP_TRY(hipMemcpyAsync(&hp, lv[nlv].gp, sizeof hp, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (st) st->n_grid_builds++;
-            metric[nlv] = (double)hp.sumsq / n / (j.occ + 1.0);        // 1 = as balanced as uniform random data
-            ++nlv;
-            const double m = metric[nlv - 1];
-            if (m <= 3.0 || cells >= cap) break;
-            cells = std::min(cap, cells * std::min(64.0, it == 0 ? m : pow(m, 1.5)));
+        GridIndex<T> base, sub1, sub2;
+        if (index_build_refit(ar, base, j.ridx, j.d_ref_pts, qs, (double)j.ridx.n / j.occ, s)) return -1;
+        // heavy cells (more than 8x the wanted occupancy): a sub-box grid over them, sized by how overfull they are;
+        // and once more over what is still heavy in that one (tight clusters inside blobs)
+        const unsigned thresh = (unsigned)(8.0 * j.occ + 8.0);
+        GridParams<T> hb;
+        HIP_TRY(hipMemcpyAsync(&hb, base.gp, sizeof hb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (st) st->n_grid_builds += 1;
+        j.ridx = base; j.n_fine = 0;
+        if ((double)hb.sumsq / (double)j.ridx.n > 4.0 * (j.occ + 1.0)) {       // still unbalanced after clipping the outliers
+            if (index_build_heavy(ar, sub1, base, j.d_ref_pts, j.occ, thresh, s)) return -1;
+            if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
+            if (st) st->n_grid_builds += 2;
+            j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
         }
-        // lv[0] is the coarsest (becomes the base grid), lv[nlv-1] the finest; keep a finer level only if it helps
-        j.ridx = lv[0]; j.n_fine = 0;
-        for (int i = nlv - 1; i >= 1 && j.n_fine < 2; --i)
-            if (metric[i] < 0.7 * metric[i - 1]) j.fine[j.n_fine++] = lv[i];
         j.skew_check = false;
         if (search_enqueue(c, s, j, st)) return -1;
         HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         hc = hc_redo; redone = true;
+        if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d lists: after finest %d, after mid %d, after base %d; ties %d\n", j.qidx.n, hc[C_X0], hc[C_X1], hc[C_U1], hc[C_T1]);
     }
     if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
     int n_left = hc[C_U3];

@@ -52,6 +52,8 @@ struct GridParams {
     T org[3];                 // grid origin: = gmin, or the low corner of the core range when far outliers were
                               // clipped (clouds refitted after an unbalanced first grid); cells at the grid border
                               // then also hold everything beyond it
+    int closed;               // 1: the index holds only the points inside [org, org + G*h) (sub-box level of an unbalanced
+                              // cloud); points beyond the grid border exist but are not in it, so border faces count
     unsigned long long sumsq; // sum over cells of count^2 (balance metric: sumsq / n = mean number of cell mates)
 };
 

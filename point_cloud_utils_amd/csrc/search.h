@@ -41,6 +41,9 @@ struct SearchArgs {
     int nq;                         // number of work items when qcount_dev is null
     int R;                          // search radius in cells
     unsigned n_ref;                 // number of dataset records; ref[n_ref] is the +inf sentinel record
+    unsigned lane_max_cand;         // a lane whose 27 cells hold more candidates than this hands its query to the wave-per-query
+                                    // pass (via the tie list) instead of scanning them serially: one heavy cell next to a query
+                                    // must not turn a wave into a millisecond-long pole
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then builds a quantile grid
     int kreq;                       // neighbours requested (<= K)
@@ -81,7 +84,7 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
     T lb = INFINITY;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        if (c0[j] > 0) {              // points with cell_j <= c0-1: coordinate < gmin + c0*h (+slack)
+        if (c0[j] > 0 || g.closed) {  // points with cell_j <= c0-1 (closed sub-box grids: also everything beyond the border): coordinate < gmin + c0*h (+slack)
             T B = face_below(g, j, c0[j]);
             T m = q[j] - B;
             m = m > (T)0 ? m * shrink : (T)0;
@@ -90,7 +93,7 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
             T f = ((t0 * t0) + (t1 * t1)) + (t2 * t2);
             lb = f < lb ? f : lb;
         }
-        if (c1[j] < g.G[j] - 1) {     // points with cell_j >= c1+1: coordinate >= gmin + (c1+1)*h (-slack)
+        if (c1[j] < g.G[j] - 1 || g.closed) {     // points with cell_j >= c1+1: coordinate >= gmin + (c1+1)*h (-slack)
             T B = face_above(g, j, c1[j]);
             T m = B - q[j];
             m = m > (T)0 ? m * shrink : (T)0;
@@ -159,7 +162,13 @@ __device__ __forceinline__ void offer4(const Pt4<T>& q, const Pt4<T>& c0, const 
 // `valid` is false for padding lanes of a partial wave (they only take part in the wave-wide list appends).
 template <typename T, int K>
 __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridParams<T>& g, const Pt4<T>& q, int qpos,
-                                            int x0, int x1, int y0, int y1, int z0, int z1, T (&bd)[K], int (&bi)[K], bool tie, bool valid) {
+                                            int x0, int x1, int y0, int y1, int z0, int z1, T (&bd)[K], int (&bi)[K], bool tie, bool valid,
+                                            bool defer = false) {
+    if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
+        wave_append(false, qpos, a.unresolved, a.n_unresolved);
+        wave_append(valid, qpos, a.ties, a.n_ties);
+        return;
+    }
     const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
     const int kreq = a.kreq;
     T kth = bd[0];
@@ -236,9 +245,13 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     constexpr int kGroup = 4;
     const char* const base = reinterpret_cast<const char*>(a.ref);
     const unsigned sentinel = a.n_ref;
+    unsigned total = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) total += re[j] - rs[j];
+    const bool defer = total > a.lane_max_cand;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const unsigned e = re[j];
+        const unsigned e = defer ? rs[j] : re[j];
         for (unsigned p = rs[j]; p < e; p += kGroup) {
             Pt4<T> c[kGroup];
 #pragma unroll
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
         }
     }
 
-    finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true);
+    finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
 
 // -------------------------------------------------------------------------------------------------------

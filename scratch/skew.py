@@ -20,7 +20,9 @@ v = rng.normal(size=(n,3)); v /= np.linalg.norm(v,axis=1,keepdims=True); w = rng
 cases["sphere_surface"] = (v, w)
 a = rng.random((n,3)); a[0] = [1000,1000,1000]; b = rng.random((n,3)); b[0] = [-1000,-1000,-1000]
 cases["outlier_bbox"] = (a, b)
+sel = sys.argv[1:]
 for name, (x, y) in cases.items():
+    if sel and name not in sel: continue
     tx, ty = torch.from_numpy(x.astype(np.float32)).cuda(), torch.from_numpy(y.astype(np.float32)).cuda()
     t = timeit(lambda: pcu.chamfer_distance(tx, ty), n=3)
     st = pcu.last_stats()
