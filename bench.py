@@ -76,7 +76,7 @@ def main():
     x_h = np.random.default_rng(1000 + 2 * rank).random((n, 3), dtype=np.float32)
     y_h = np.random.default_rng(1001 + 2 * rank).random((n, 3), dtype=np.float32)
     x, y = torch.from_numpy(x_h).to(dev), torch.from_numpy(y_h).to(dev)
-    results = torch.zeros(max(args.steps, 1), dtype=torch.float32, device=dev)
+    results = [0.0] * max(args.steps, 1)          # per-step scalars stay on the host until the final gather
 
     def sync_all():
         torch.cuda.synchronize()
@@ -84,25 +84,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    pcu.set_timing(0)
     for _ in range(args.warmup):
         pcu.chamfer_distance(x, y)
-    k_ms, k_n, idx_ms, tot_ms = 0.0, 0, 0.0, 0.0
+    # Roofline input: HIP events around the main search launches (k_search*<float>, one per direction), recorded by the
+    # library on its launch stream INSIDE the timed region -- on every 4th step only, because each event is a ~6 us
+    # bubble between kernels (8 events per step cost ~10 % of the step).
+    KEV_EVERY = 4
+    k_ms, k_n = 0.0, 0
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ch = pcu.chamfer_distance(x, y)
-        results[s] = float(ch)
-        st = pcu.last_stats()
-        k_ms += st["ms_kernel_search"]; k_n += st["n_kernel_search"]; idx_ms += st["ms_index"]; tot_ms += st["ms_total"]
+        timed = s % KEV_EVERY == 0
+        if timed:
+            pcu.set_timing(1)
+        results[s] = float(pcu.chamfer_distance(x, y))
+        if timed:
+            st = pcu.last_stats()
+            k_ms += st["ms_kernel_search"]; k_n += st["n_kernel_search"]
+            pcu.set_timing(0)
+    res_t = torch.tensor(results, dtype=torch.float32, device=dev)
     if distributed:   # the only collective of the job: gather the per-pair scalars (K floats per rank)
-        gathered = [torch.empty_like(results) for _ in range(world)]
-        dist.all_gather(gathered, results)
+        gathered = [torch.empty_like(res_t) for _ in range(world)]
+        dist.all_gather(gathered, res_t)
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # phase breakdown (diagnostic, OUTSIDE the timed region: 3 extra steps with phase events on)
+    idx_ms = tot_ms = srch_ms = 0.0
+    if rank == 0:
+        pcu.set_timing(2)
+        for _ in range(3):
+            pcu.chamfer_distance(x, y)
+            st = pcu.last_stats()
+            idx_ms += st["ms_index"] / 3; srch_ms += st["ms_search"] / 3; tot_ms += st["ms_total"] / 3
+        pcu.set_timing(0)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -129,9 +148,11 @@ def main():
                        "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_search<float,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n},
-            "device_ms_per_step": {"index_build": idx_ms / steps, "search_kernels": k_ms / steps, "total": tot_ms / steps},
-            "chamfer": float(results[0].item()),
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n,
+                         "timing": f"HIP events around both main search launches of every {KEV_EVERY}th timed step"},
+            "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
+                                   "note": "3 extra steps outside the timed region, phase events on"},
+            "chamfer": float(results[0]),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_h, y_h)

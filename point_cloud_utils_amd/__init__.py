@@ -27,11 +27,25 @@ from . import _lib
 from ._lib import Stats, set_cell_occupancy, device_count  # noqa: F401
 
 __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_distance", "chamfer_distance",
-           "last_stats", "set_cell_occupancy", "device_count"]
+           "last_stats", "set_timing", "set_cell_occupancy", "device_count"]
 
 _last_stats = {}
 # PCU_HIP_NO_TIE_ORDER=1: skip the kd-tree tie-order resolver (exact ties then ordered by (d2, row)); for experiments.
 _ENV_FLAGS = _lib.NO_TIE_ORDER if __import__("os").environ.get("PCU_HIP_NO_TIE_ORDER", "0") not in ("", "0") else 0
+_TIMING = [int(__import__("os").environ.get("PCU_HIP_TIMING", "0") or 0)]
+
+
+def set_timing(level):
+    """Device-side timing written into last_stats(): 0 = none (default; counters only), 1 = the main search launches
+    (ms_kernel_search / n_kernel_search), 2 = also the phases of the call (ms_index / ms_search / ms_total / ms_tie).
+    Every HIP event costs a few microseconds of bubble between kernels, which is why it is opt-in. Returns the old level."""
+    old = _TIMING[0]
+    _TIMING[0] = int(level)
+    return old
+
+
+def _flags():
+    return _ENV_FLAGS | (_lib.TIME_KERNELS if _TIMING[0] >= 1 else 0) | (_lib.TIME_PHASES if _TIMING[0] >= 2 else 0)
 
 
 def last_stats():
@@ -99,7 +113,7 @@ class _Dev:
             # the library call is ordered after work queued on torch's current stream, unless this thread asked for its
             # context's private stream (batched workers; they synchronise with the producer themselves)
             self.stream = None if _lib.use_private_stream() else torch.cuda.current_stream(a.device).cuda_stream
-            self.flags = _lib.PTRS_ON_DEVICE | _ENV_FLAGS
+            self.flags = _lib.PTRS_ON_DEVICE | _flags()
             self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
             self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64
             self.t_dtype = a.dtype
@@ -107,7 +121,7 @@ class _Dev:
             self.a, self.b = np.ascontiguousarray(a), np.ascontiguousarray(b)
             self.device = _lib.default_device()
             self.stream = None
-            self.flags = _ENV_FLAGS
+            self.flags = _flags()
             self.pa, self.pb = self.a.ctypes.data, self.b.ctypes.data
             self.np_dtype = self.a.dtype.type
         self.suffix = "f32" if self.np_dtype == np.float32 else "f64"

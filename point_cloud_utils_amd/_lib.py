@@ -10,6 +10,8 @@ LIB_PATH = os.path.join(_HERE, "libpcu_hip.so")
 PTRS_ON_DEVICE = 1
 SQUARED = 2
 NO_TIE_ORDER = 4
+TIME_PHASES = 8
+TIME_KERNELS = 16
 
 ERR_INVALID = -1
 

@@ -31,6 +31,21 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// "Last block finishes the job" without __threadfence(): on gfx950 a device-scope fence is an L2 write-back +
+// invalidate (buffer_wbl2 / buffer_inv) per block, which costs more than the launch it saves. Instead the few values
+// that cross blocks are written with agent-scope atomic stores (write-through, `sc1`), the writer waits for them
+// (s_waitcnt) before taking its ticket with a relaxed atomic, and the last block reads them back with agent-scope
+// atomic loads (`sc1`, served coherently).
+template <typename V>
+__device__ __forceinline__ void publish(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V>
+__device__ __forceinline__ V peek(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// to be called by ONE thread after a __syncthreads() that follows the publishing threads' wait_stores()
+__device__ __forceinline__ bool take_ticket(unsigned* ticket, unsigned nblocks) {
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
+}
+
 constexpr int kBboxBlocks = 256;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz
 
 // pts: row-major (n,3). Lane i reads 3 consecutive scalars at 3*i: a wave covers one contiguous 768 B
@@ -38,8 +53,15 @@ constexpr int kBboxBlocks = 256;   // one per CU; partial[b][0..2] = min xyz, [3
 // writes one partial; k_make_grid folds the kBboxBlocks partials. The same launch zero-fills the cell
 // counters (so the build needs no separate memset launch).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ pts, int n, T* __restrict__ partial,
-                                                         unsigned* __restrict__ counts, int n_counts) {
+__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel);
+
+// With `ticket` (a zeroed, self-resetting counter) the block that finishes last also folds the partials and makes the
+// grid (make_grid_body), which saves the separate single-block k_make_grid launch (~4.5 us of launch floor per build).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ pts, int n, T* partial,
+                                                         unsigned* __restrict__ counts, int n_counts,
+                                                         unsigned* ticket = nullptr, GridParams<T>* gp = nullptr, double occupancy = 0,
+                                                         int max_cells = 0, Pt4<T>* sentinel = nullptr) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -63,16 +85,24 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ p
         const int j = threadIdx.x;
         T a = s_lo[0][j], b = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
-        partial[blockIdx.x * 6 + j] = a;
-        partial[blockIdx.x * 6 + 3 + j] = b;
+        publish(&partial[blockIdx.x * 6 + j], a);
+        publish(&partial[blockIdx.x * 6 + 3 + j], b);
+        wait_stores();
     }
+    if (!ticket) return;
+    __shared__ bool s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = take_ticket(ticket, gridDim.x);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *ticket = 0u;
+    make_grid_body<T>(gp, partial, (int)gridDim.x, n, occupancy, max_cells, sentinel);
 }
 
 // One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T* __restrict__ partial, int nparts,
-                                                      int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
+__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
@@ -80,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
         for (int b = threadIdx.x; b < nparts; b += kBlock)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T a = partial[b * 6 + j], c = partial[b * 6 + 3 + j];
+                T a = peek(&partial[b * 6 + j]), c = peek(&partial[b * 6 + 3 + j]);
                 lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
             }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -92,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (sentinel) { sentinel->x = sentinel->y = sentinel->z = (T)INFINITY; sentinel->idx = 0x7fffffff; }   // record n: see k_search
+    if (sentinel) for (int j = 0; j < 8; ++j) { sentinel[j].x = sentinel[j].y = sentinel[j].z = (T)INFINITY; sentinel[j].idx = 0x7fffffff; }   // records n..n+7: see k_search / k_search1
     double ext[3];
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];
@@ -135,6 +165,11 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T
     gp->ncells = G[0] * G[1] * G[2];
     for (int j = 0; j < 3; ++j) gp->org[j] = gp->gmin[j];
     gp->sumsq = 0ull; gp->closed = 0;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T* partial, int nparts,
+                                                      int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
+    make_grid_body<T>(gp, partial, nparts, n, occupancy, max_cells, sentinel);
 }
 
 template <typename T>
@@ -190,6 +225,30 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* t
     return ex;
 }
 
+// Same for a block of NT threads (NT a multiple of 64).
+template <int NT>
+__device__ __forceinline__ unsigned block_exclusive_scan_nt(unsigned v, unsigned* total) {
+    __shared__ unsigned s_w[NT / 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned t = threadIdx.x < NT / 64 ? s_w[threadIdx.x] : 0u, ti = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned u = __shfl_up(ti, o, 64); if (lane >= o) ti += u; }
+        if (threadIdx.x < NT / 64) s_w[threadIdx.x] = ti - t;
+        if (threadIdx.x == NT / 64 - 1) s_w[NT / 64] = ti;
+    }
+    __syncthreads();
+    unsigned ex = inc - v + s_w[wave];
+    *total = s_w[NT / 64];
+    __syncthreads();
+    return ex;
+}
+
 // m is read from device memory (gp->ncells) so no host round trip is needed between build stages.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ counts, GridParams<T>* gp,
@@ -236,16 +295,253 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* counts, const G
     }
 }
 
+// `rank` is turned into the row's slot in place (rank[i] := cell_start[cell_of[i]] + rank[i]): the row -> slot map
+// k_unpermute needs.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, int n, const unsigned* __restrict__ cell_of,
-                                                    const unsigned* __restrict__ rank, const unsigned* __restrict__ cell_start,
+                                                    unsigned* rank, const unsigned* __restrict__ cell_start,
                                                     Pt4<T>* __restrict__ sorted) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     if (cell_of[i] == 0xffffffffu) return;            // not part of a closed (sub-box) index
     Pt4<T> p;
     p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; p.idx = i;
-    sorted[cell_start[cell_of[i]] + rank[i]] = p;
+    const unsigned pos = cell_start[cell_of[i]] + rank[i];
+    sorted[pos] = p;
+    rank[i] = pos;
+}
+
+// ---- bucketed build (the default for the whole-cloud indexes) -------------------------------------------------------
+// The count/scan/scatter pipeline above spends most of its time in one returning *device-scope* atomic per point (1M
+// atomics = 41 us on MI355X: they are executed memory-side, 39 MB of write traffic for 4 MB of counters). The bucketed
+// build is a two-level MSD counting sort on the linear (snake) cell id that keeps all per-point atomics in LDS:
+//   k_bucket_count    blocks of 4096 points: LDS histogram over *buckets* (runs of 2^shift consecutive cells, ~2k
+//                     points each); one returning global atomic per (block, non-empty bucket) reserves the block's
+//                     slice of the bucket                                    [~120k global atomics instead of 1M]
+//   k_bucket_scatter  same blocks: prefix of the bucket totals, LDS rank inside (block, bucket), records written into
+//                     `tmp` grouped by bucket (runs of ~8 records)
+//   k_bucket_sort     one 1024-thread block per bucket: LDS histogram over the bucket's cells, scan -> cell_start,
+//                     records written to their final slot in `sorted` (the bucket's 32-64 KB window: L2 merges lines)
+//   k_bucket_large    buckets holding more than kLargeBucket points (clusters, surfaces tangent to a row of cells, a far
+//                     outlier) are not sorted by one block: k_bucket_scatter takes their per-cell ranks with the
+//                     returning global atomic of the old scheme (wave-aggregated when a whole wave hits one cell),
+//                     k_bucket_sort only scans their cell counters, and this grid-strided kernel places the records.
+//                     It exits at once when there is no such bucket.
+// Any valid cell order gives the same search results; the order inside a cell is arbitrary in both builds.
+constexpr int kBkThreads = 1024;                    // 16 waves per block: the passes are latency-bound, one block per CU
+constexpr int kBkPts = 4;                           // points per thread of the bucket passes
+constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
+constexpr int kBkMaxBuckets = 4096;
+constexpr int kBkMaxCellsPerBucket = 4096;
+constexpr int kSortThreads = 1024;
+constexpr int kSortIters = 16;
+constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 16384 points
+
+template <typename T>
+__device__ __forceinline__ unsigned cell_linear(const GridParams<T>& g, T x, T y, T z) {
+    const int cx = grid_cell(g, 0, x), cy = grid_cell(g, 1, y), cz = grid_cell(g, 2, z);
+    return (unsigned)row_run_lo(g.G[0], grid_row(g.G[1], cy, cz), cx, cx);
+}
+
+// counter[key] += 1 for the lanes with `valid`, returning the lane's rank. A wave whose valid lanes all carry the same
+// key issues one atomic. Must be called from wave-uniform control flow.
+__device__ __forceinline__ unsigned count_rank(unsigned* counter, unsigned key, bool valid) {
+    const unsigned long long act = __ballot(valid);
+    if (act == 0) return 0;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)act) - 1;
+    const unsigned k0 = (unsigned)__shfl((int)key, first, 64);
+    unsigned r = 0;
+    if (__all(!valid || key == k0)) {
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(&counter[k0], (unsigned)__popcll(act));
+        base = (unsigned)__shfl((int)base, first, 64);
+        r = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
+    } else if (valid) {
+        r = atomicAdd(&counter[key], 1u);
+    }
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_count(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
+                                                             unsigned* bucket_total, unsigned* __restrict__ block_base, int nb_stride) {
+    __shared__ unsigned s_cnt[kBkMaxBuckets];
+    const GridParams<T>& g = *gp;
+    const int NB = (g.ncells + (1 << shift) - 1) >> shift;
+    for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kBkBlockPts;
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const int i = base + j * kBkThreads + (int)threadIdx.x;
+        const bool valid = i < n;
+        unsigned b = 0;
+        if (valid) b = cell_linear(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]) >> shift;
+        (void)count_rank(s_cnt, b, valid);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += kBkThreads) {
+        const unsigned c = s_cnt[i];
+        block_base[(size_t)blockIdx.x * nb_stride + i] = c ? atomicAdd(&bucket_total[i], c) : 0u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
+                                                               const unsigned* __restrict__ bucket_total, const unsigned* __restrict__ block_base,
+                                                               int nb_stride, unsigned* __restrict__ bucket_start, Pt4<T>* __restrict__ tmp,
+                                                               unsigned* cell_counts, unsigned* __restrict__ rank_tmp) {
+    __shared__ unsigned s_cnt[kBkMaxBuckets];      // running count of this block per bucket
+    __shared__ unsigned s_off[kBkMaxBuckets];      // slot of this block's first record in the bucket; bit 31: large bucket
+    const GridParams<T>& g = *gp;
+    const int NB = (g.ncells + (1 << shift) - 1) >> shift;
+    {   // exclusive prefix of the bucket totals (every block computes it: NB <= 4096 values)
+        const int per = (NB + kBkThreads - 1) / kBkThreads;
+        const int i0 = (int)threadIdx.x * per;
+        unsigned loc = 0;
+        for (int q = 0; q < per; ++q) if (i0 + q < NB) loc += bucket_total[i0 + q];
+        unsigned total;
+        unsigned ex = block_exclusive_scan_nt<kBkThreads>(loc, &total);
+        for (int q = 0; q < per; ++q) {
+            const int i = i0 + q;
+            if (i < NB) {
+                const unsigned t = bucket_total[i];
+                s_off[i] = (ex + block_base[(size_t)blockIdx.x * nb_stride + i]) | (t > kLargeBucket ? 0x80000000u : 0u);
+                s_cnt[i] = 0;
+                if (blockIdx.x == 0) bucket_start[i] = ex;
+                ex += t;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) bucket_start[NB] = total;
+    }
+    __syncthreads();
+    const int base = blockIdx.x * kBkBlockPts;
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const int i = base + j * kBkThreads + (int)threadIdx.x;
+        const bool valid = i < n;
+        Pt4<T> p; p.x = p.y = p.z = (T)0; p.idx = i;
+        unsigned c = 0;
+        if (valid) { p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; c = cell_linear(g, p.x, p.y, p.z); }
+        const unsigned b = c >> shift;
+        const unsigned r = count_rank(s_cnt, b, valid);
+        unsigned so = 0;
+        if (valid) so = s_off[b];
+        const unsigned pos = (so & 0x7fffffffu) + r;
+        if (valid) tmp[pos] = p;
+        const bool lg = valid && (so >> 31);
+        if (__any(lg)) {               // large bucket: per-cell rank by the returning global atomic
+            const unsigned rk = count_rank(cell_counts, c, lg);
+            if (lg) rank_tmp[pos] = rk;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
+                                                              const Pt4<T>* __restrict__ tmp, unsigned* cell_start, Pt4<T>* __restrict__ sorted,
+                                                              unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large) {
+    __shared__ unsigned s_cnt[kBkMaxCellsPerBucket];
+    __shared__ unsigned s_w[kSortThreads / 64 + 1];
+    __shared__ unsigned long long s_q[kSortThreads / 64];
+    const GridParams<T>& g = *gp;
+    const int CB = 1 << shift;
+    const int NB = (g.ncells + CB - 1) >> shift;
+    const int b = blockIdx.x;
+    if (b >= NB) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned c0 = (unsigned)b << shift;
+    const int ncl = min(CB, g.ncells - (int)c0);
+    const unsigned s = bucket_start[b], e = bucket_start[b + 1];
+    const bool large = e - s > kLargeBucket;
+    for (int i = tid; i < CB; i += kSortThreads) s_cnt[i] = (large && i < ncl) ? cell_start[c0 + i] : 0u;
+    __syncthreads();
+    unsigned rr[kSortIters];           // (cell in bucket) << 16 | rank in cell      (small buckets: <= 16384 records)
+    if (!large) {
+#pragma unroll
+        for (int it = 0; it < kSortIters; ++it) {
+            const unsigned p = s + (unsigned)(it * kSortThreads + tid);
+            rr[it] = 0;
+            if (p < e) {
+                const Pt4<T> rec = tmp[p];
+                const unsigned c = cell_linear(g, rec.x, rec.y, rec.z) - c0;
+                rr[it] = (c << 16) | atomicAdd(&s_cnt[c], 1u);
+            }
+        }
+        __syncthreads();
+    }
+    // exclusive scan of the CB counters (thread-contiguous items), cell_start, balance metric
+    const int per = CB >= kSortThreads ? CB / kSortThreads : 1;
+    const int i0 = tid * per;
+    unsigned v[kBkMaxCellsPerBucket / kSortThreads], sum = 0; unsigned long long sq = 0;
+#pragma unroll
+    for (int q = 0; q < kBkMaxCellsPerBucket / kSortThreads; ++q) {
+        v[q] = (q < per && i0 + q < CB) ? s_cnt[i0 + q] : 0u;
+        sum += v[q]; sq += (unsigned long long)v[q] * v[q];
+    }
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (lane == 63) s_w[wave] = inc;
+    if (lane == 0) s_q[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0; unsigned long long Q = 0;
+        for (int w = 0; w < kSortThreads / 64; ++w) { const unsigned t = s_w[w]; s_w[w] = run; run += t; Q += s_q[w]; }
+        if (Q) atomicAdd(&gp->sumsq, Q);
+        if (large) large_list[atomicAdd(n_large, 1u)] = (unsigned)b;
+        if (b == NB - 1) cell_start[g.ncells] = e;
+    }
+    __syncthreads();
+    unsigned ex = inc - sum + s_w[wave];
+#pragma unroll
+    for (int q = 0; q < kBkMaxCellsPerBucket / kSortThreads; ++q) {
+        if (q < per && i0 + q < CB) {
+            s_cnt[i0 + q] = ex;
+            if (i0 + q < ncl) cell_start[c0 + i0 + q] = s + ex;
+            ex += v[q];
+        }
+    }
+    if (large) return;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kSortIters; ++it) {
+        const unsigned p = s + (unsigned)(it * kSortThreads + tid);
+        if (p < e) {
+            const Pt4<T> rec = tmp[p];
+            const unsigned pos = s + s_cnt[rr[it] >> 16] + (rr[it] & 0xffffu);
+            sorted[pos] = rec;
+            if (pos_of) pos_of[rec.idx] = pos;
+        }
+    }
+}
+
+template <typename T>
+struct LargeJob {
+    const GridParams<T>* gp; const unsigned* bucket_start; const unsigned* large_list; const unsigned* n_large;
+    const Pt4<T>* tmp; const unsigned* rank_tmp; const unsigned* cell_start; Pt4<T>* sorted; unsigned* pos_of;
+};
+// One launch serves the indexes built back to back (both clouds of a two-sided call): njobs <= 2.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bucket_large(const LargeJob<T> j0, const LargeJob<T> j1, int njobs) {
+    for (int jj = 0; jj < njobs; ++jj) {
+        const LargeJob<T>& J = jj ? j1 : j0;
+        const unsigned nl = *J.n_large;
+        if (nl == 0) continue;
+        const GridParams<T>& g = *J.gp;
+        for (unsigned l = 0; l < nl; ++l) {
+            const unsigned b = J.large_list[l];
+            const unsigned s = J.bucket_start[b], e = J.bucket_start[b + 1];
+            for (unsigned p = s + blockIdx.x * kBlock + threadIdx.x; p < e; p += gridDim.x * kBlock) {
+                const Pt4<T> rec = J.tmp[p];
+                const unsigned pos = J.cell_start[cell_linear(g, rec.x, rec.y, rec.z)] + J.rank_tmp[p];
+                J.sorted[pos] = rec;
+                if (J.pos_of) J.pos_of[rec.idx] = pos;
+            }
+        }
+    }
 }
 
 // ---- refitting the grid of an unbalanced cloud -----------------------------------------------------------------------
@@ -316,7 +612,7 @@ __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, 
                                   int max_cells, Pt4<T>* sentinel, int closed, const double* target_dev) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (target_dev) target_cells = *target_dev;
-    if (sentinel) { sentinel->x = sentinel->y = sentinel->z = (T)INFINITY; sentinel->idx = 0x7fffffff; }
+    if (sentinel) for (int j = 0; j < 8; ++j) { sentinel[j].x = sentinel[j].y = sentinel[j].z = (T)INFINITY; sentinel[j].idx = 0x7fffffff; }
     double ext[3];
     for (int j = 0; j < 3; ++j) { gp->gmin[j] = base->gmin[j]; gp->gmax[j] = base->gmax[j]; gp->org[j] = qs->lo[j]; ext[j] = (double)qs->hi[j] - (double)qs->lo[j]; }
     double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);

@@ -48,6 +48,9 @@ struct pcu_hip_ctx {
     int n_kev = 0;
     double occupancy = 0;                      // <=0: default
     int* h_pinned = nullptr;                   // small pinned readback buffer
+    bool time_phases = false, time_kernels = false;          // HIP-event timing of this call (flags PCU_HIP_TIME_*): each event is a
+                                                             // ~6 us bubble in the kernel pipeline, so both are opt-in
+    unsigned* tickets = nullptr; unsigned ticket_next = 0;   // 64 zeroed, self-resetting last-block counters (index builds)
     // tie-order resolver: its own grow-only workspace (stable addresses across calls, so the captured
     // level-pair graph below stays valid) and one cached executable graph per scalar type
     char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
@@ -137,6 +140,11 @@ struct GridIndex {
     unsigned* cell_of = nullptr; unsigned* rank = nullptr; unsigned* block_sums = nullptr;
     T* bbox_partial = nullptr;
     int n = 0, max_cells = 0, scan_blocks = 0;
+    unsigned* pos_of = nullptr;           // row -> slot in `sorted` (only when asked for: k_unpermute)
+    unsigned* ticket = nullptr;           // last-block ticket of the build's first launch
+    // bucketed build (grid.h): cells per bucket = 1 << shift; nb_max = host bound on the number of buckets
+    bool bucketed = false; int shift = 0, nb_max = 0, n_zero = 0;
+    Pt4<T>* tmp = nullptr; unsigned *bucket_total = nullptr, *bucket_start = nullptr, *block_base = nullptr, *large_list = nullptr, *n_large = nullptr;
 };
 
 static int max_cells_for(int64_t n, double occ) {
@@ -144,35 +152,92 @@ static int max_cells_for(int64_t n, double occ) {
     if (c > 64.0 * 1024 * 1024) c = 64.0 * 1024 * 1024;
     return (int)c;
 }
+// Bucketed build: applicable when the cells split into <= 4096 buckets of <= 4096 cells (~2k points each) and the
+// (block, bucket) reservation table stays small; otherwise (tiny or huge clouds, very coarse grids) the atomic build.
+static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
+    static const bool off = [] { const char* e = getenv("PCU_HIP_INDEX"); return e && strcmp(e, "atomic") == 0; }();
+    if (off || n < 32768 || occ > 64.0) return false;
+    const int mc = max_cells_for(n, occ);
+    int sh = 5;
+    while (sh < 12 && (double)(2 << sh) * occ <= 2048.0) ++sh;             // largest bucket with <= ~2048 expected points
+    while (sh < 12 && ((mc >> sh) + 1) > kBkMaxBuckets) ++sh;
+    const int nb = (mc >> sh) + 1;
+    if (nb > kBkMaxBuckets) return false;
+    if ((double)(1 << sh) * occ > 0.5 * (double)kLargeBucket) return false;
+    const int64_t blocks = (n + kBkBlockPts - 1) / kBkBlockPts;
+    if (blocks * (int64_t)nb > 8ll * 1024 * 1024) return false;
+    *shift = sh; *nb_max = nb;
+    return true;
+}
 template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
-    return align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1) * 4, 256) + align_up((size_t)(n + 1) * sizeof(Pt4<T>), 256) +
-           2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
+    size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8) * 4, 256) + align_up((size_t)(n + 8) * sizeof(Pt4<T>), 256) +
+               2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
+    int sh = 0, nb = 0;
+    if (bucket_plan(n, occ, &sh, &nb))
+        b += align_up((size_t)n * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
+             align_up((size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * nb * 4, 256);
+    return b;
 }
 template <typename T>
-static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ) {
+static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool want_pos = false, bool allow_bucketed = true) {
     g.n = (int)n; g.max_cells = max_cells_for(n, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
+    g.bucketed = allow_bucketed && bucket_plan(n, occ, &g.shift, &g.nb_max);
     if (aalloc(a, &g.gp, 1)) return -1;
-    if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1)) return -1;
-    if (aalloc(a, &g.sorted, (size_t)n + 1)) return -1;        // + the +inf sentinel record
+    if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1 + kBkMaxBuckets + 8)) return -1;    // + bucket totals + large-bucket count (zeroed together)
+    if (aalloc(a, &g.sorted, (size_t)n + 8)) return -1;        // + the +inf sentinel records
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
     if (aalloc(a, &g.bbox_partial, (size_t)kBboxBlocks * 6)) return -1;
+    g.n_zero = g.max_cells + 1;
+    g.ticket = a.c->tickets + (a.c->ticket_next++ & 63);
+    if (g.bucketed) {
+        g.bucket_total = g.cell_start + g.max_cells + 1; g.n_large = g.bucket_total + g.nb_max; g.n_zero = g.max_cells + 1 + g.nb_max + 1;
+        if (aalloc(a, &g.tmp, (size_t)n)) return -1;
+        if (aalloc(a, &g.bucket_start, (size_t)g.nb_max + 1) || aalloc(a, &g.large_list, (size_t)g.nb_max + 1)) return -1;
+        if (aalloc(a, &g.block_base, (size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * g.nb_max)) return -1;
+        g.pos_of = want_pos ? g.cell_of : nullptr;      // cell_of is not used by this build
+    } else {
+        g.pos_of = g.rank;                              // k_scatter turns rank into the slot, in place
+    }
     return 0;
 }
-// Enqueue the whole build on `s`: 6 launches, no memset, no host synchronisation.
+// Placement of the records of over-full buckets (grid.h): one launch for up to two indexes built back to back.
 template <typename T>
-static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s) {
+static LargeJob<T> large_job(const GridIndex<T>& g) { return LargeJob<T>{g.gp, g.bucket_start, g.large_list, g.n_large, g.tmp, g.rank, g.cell_start, g.sorted, g.pos_of}; }
+template <typename T>
+static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipStream_t s) {
+    const bool ua = a.bucketed, ub = b && b->bucketed;
+    if (!ua && !ub) return;
+    const LargeJob<T> ja = large_job(ua ? a : *b), jb = large_job(ua && ub ? *b : (ua ? a : *b));
+    hipLaunchKernelGGL(k_bucket_large<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, ja, jb, (ua && ub) ? 2 : 1);
+}
+// Enqueue the whole build on `s`: 4-5 launches, no memset, no host synchronisation. defer_large: the caller issues
+// index_large_pass itself (shared with the next build).
+template <typename T>
+static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false) {
     const int n = g.n;
     const int nb = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.max_cells + 1);
-    hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells, g.sorted + n);
-    hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
-    hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
-    hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
-    hipLaunchKernelGGL(k_scatter<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.cell_of, g.rank, g.cell_start, g.sorted);
+    // bbox partials + zero-fill of the counters; the last block to finish also makes the grid (ticket: one of the context's
+    // zeroed, self-resetting counters -- a different one for each build in flight)
+    hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.n_zero,
+                       g.ticket, g.gp, occ, g.max_cells, g.sorted + n);
+    if (g.bucketed) {
+        const int nblk = (n + kBkBlockPts - 1) / kBkBlockPts;
+        hipLaunchKernelGGL(k_bucket_count<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max);
+        hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max,
+                           g.bucket_start, g.tmp, g.cell_start, g.rank);
+        hipLaunchKernelGGL(k_bucket_sort<T>, dim3(g.nb_max), dim3(kSortThreads), 0, s, g.gp, g.shift, g.bucket_start, g.tmp, g.cell_start, g.sorted,
+                           g.pos_of, g.large_list, g.n_large);
+        if (!defer_large) index_large_pass<T>(g, nullptr, s);
+    } else {
+        hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
+        hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
+        hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
+        hipLaunchKernelGGL(k_scatter<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.cell_of, g.rank, g.cell_start, g.sorted);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -199,7 +264,7 @@ static int index_build_refit(Arena& ar, GridIndex<T>& g, const GridIndex<T>& bas
     // closed: sub-box level (only the points inside the box are indexed); target_dev: cell count decided on the device
     const int n = base.n;
     if (target_cells < 1.0) target_cells = 1.0;
-    if (index_alloc(ar, g, n, (double)n / target_cells)) return -1;
+    if (index_alloc(ar, g, n, (double)n / target_cells, false, /*allow_bucketed=*/false)) return -1;
     const int nb = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n,
                        closed ? 1 : 0, target_dev);
@@ -239,15 +304,21 @@ constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced wh
 constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
 template <typename T>
-static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s) {
+static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s, bool open_index) {
     if (nwork <= 0) return 0;
     // grid = multiple of 8 (XCD-aware block map). Default: the per-lane gather kernel; PCU_HIP_TILE=1 selects the
     // LDS-tiled kernel (one wave per block). Measured on MI355X (profiles/r01_search_kernel_ab.txt): both are
     // instruction-issue bound at ~2-3k instructions per wave; the tile kernel issues 15x fewer vector memory
     // instructions but more VALU/SALU/LDS bookkeeping and is slower (129 vs 83 us at 1M/k=1), so gather stays default.
     static const bool use_gather = getenv("PCU_HIP_TILE") == nullptr;
+    static const bool use_k1 = getenv("PCU_HIP_NO_K1") == nullptr;
     const int tb = use_gather ? kBlock : 64;
     dim3 grid((((nwork + tb - 1) / tb) + 7) / 8 * 8), block(tb);
+    if (K == 1 && use_gather && use_k1 && open_index) {        // k = 1 on an open index: the group-wise kernel
+        hipLaunchKernelGGL((k_search1<T>), grid, block, 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define PCU_CASE(KK) case KK: if (use_gather) hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); \
                               else hipLaunchKernelGGL((k_search_tile<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
@@ -313,6 +384,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     SearchArgs<T> a;
     a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted; a.n_ref = (unsigned)ridx.n;
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
+    a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
     a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
@@ -320,13 +392,14 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     return a;
 }
 
-// Enqueue (no host sync): lane-per-query pass at R=1 over all queries, then three wave-per-query passes fed
-// by device-side lists: possible ties at R=1, stragglers at R=2, their stragglers at R=4.
+// Enqueue (no host sync): lane-per-query pass at R=1 over all queries, then ONE wave-per-query launch fed by two
+// device-side lists: possible ties (radius 1, total order) and stragglers (radius 2). What is still uncertified after
+// that (list u2; next to nothing on balanced clouds) is finished by search_finish's host-driven loop.
 template <typename T>
-static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st) {
+static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true) {
     const SearchScratch<T>& sc = j.sc;
     const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
-    HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
+    if (zero_counters) HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
     SearchArgs<T> b = base_args(j, j.ridx);
     b.ties = sc.tt; b.n_ties = sc.counters + C_TT;
     // Wave-per-query from the start when lane-per-query would leave the GPU empty (few queries: a 2,885-vertex mesh
@@ -345,29 +418,28 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
             // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
             if (last && j.skew_check && j.n_fine == 0) a.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
-            const bool time_it = st && lv == 0 && c->n_kev + 2 <= 8;
+            const bool time_it = st && c->time_kernels && lv == 0 && c->n_kev + 2 <= 8;
             if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
-            if (launch_search_fast<T>(KF, a, j.qidx.n, s)) return -1;
+            if (launch_search_fast<T>(KF, a, j.qidx.n, s, /*open_index=*/last)) return -1;
             if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
             lst = a.unresolved; cnt = a.n_unresolved;
         }
-        b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order
+        b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
+        b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
         if (launch_search_wave<T>(KL, b, s)) return -1;
+        if (st) st->n_passes += 2 + j.n_fine;
     } else {
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
         if (j.skew_check) b.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
         if (launch_search_wave<T>(KL, b, s)) return -1;
         b.nq = 0; b.skew_limit = 0.f;
+        b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;             // stragglers, radius 2
+        b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
+        if (launch_search_wave<T>(KL, b, s)) return -1;
+        if (st) st->n_passes += 2;
     }
-    b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;                 // stragglers, radius 2
-    b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
-    if (launch_search_wave<T>(KL, b, s)) return -1;
-    b.qlist = sc.u2; b.qcount_dev = sc.counters + C_U2; b.R = 4;                 // radius 4
-    b.unresolved = sc.u3; b.n_unresolved = sc.counters + C_U3;
-    if (launch_search_wave<T>(KL, b, s)) return -1;
-    if (st) st->n_passes += 4;
     return 0;
 }
 
@@ -486,7 +558,8 @@ template <typename T>
 static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, int n_tt, pcu_hip_stats* st) {
     KdBuild<T> b; int* err = nullptr; int levels = 0;
     hipEvent_t e0 = c->ev[4], e1 = c->ev[5];
-    if (st) (void)hipEventRecord(e0, s);
+    const bool timed = st && c->time_phases;
+    if (timed) (void)hipEventRecord(e0, s);
     if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr)) return -1;
     KdSearchArgs<T> a;
     a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
@@ -497,12 +570,12 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     a.stack = frames;
     hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
     HIP_TRY(hipGetLastError());
-    if (st) (void)hipEventRecord(e1, s);
+    if (timed) (void)hipEventRecord(e1, s);
     int herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
-    if (st) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
+    if (timed) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
     return 0;
 }
 
@@ -545,7 +618,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d lists: after finest %d, after mid %d, after base %d; ties %d\n", j.qidx.n, hc[C_X0], hc[C_X1], hc[C_U1], hc[C_T1]);
     }
     if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
-    int n_left = hc[C_U3];
+    int n_left = hc[C_U2];
     if (n_left == 0) {
         if (st) st->n_tie_true += hc[C_TT];
         j.n_tt = hc[C_TT];
@@ -553,19 +626,19 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         return redone ? 1 : 0;
     }
     const int KL = std::max(2, pow2_at_least(j.k + 1));
-    int* cur = j.sc.u3; int* nxt = j.sc.u1;
+    int* cur = j.sc.u2; int* nxt = j.sc.u1;
     double occ = j.occ;
     GridIndex<T> ridx = j.ridx;
     GridParams<T> hg;
     HIP_TRY(hipMemcpy(&hg, ridx.gp, sizeof hg, hipMemcpyDeviceToHost));
-    int R = 4;                                            // already done on the fine grid
+    int R = 2;                                            // already done on the fine grid
     for (int pass = 0; pass < 64 && n_left > 0; ++pass) {
         const int gmax = std::max(hg.G[0], std::max(hg.G[1], hg.G[2]));
         if (R >= gmax) return fail(PCU_HIP_ERR_RUNTIME, "internal: search did not certify with the whole grid scanned");
         if (R >= 4 && gmax > 8) {                         // coarser dataset grid: cell edge x8, restart at R=1
             occ *= 512.0;
             GridIndex<T> coarse;
-            if (index_alloc(ar, coarse, ridx.n, occ)) return -1;
+            if (index_alloc(ar, coarse, ridx.n, occ, false, false)) return -1;
             if (index_build(coarse, j.d_ref_pts, occ, s)) return -1;
             if (st) st->n_grid_builds++;
             ridx = coarse; R = 1;
@@ -583,7 +656,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         HIP_TRY(hipStreamSynchronize(s));
         if (st) st->n_passes++;
         n_left = left;
-        int* done = cur; cur = nxt; nxt = (done == j.sc.u3) ? j.sc.u2 : done;
+        int* done = cur; cur = nxt; nxt = done;
     }
     if (n_left > 0) return fail(PCU_HIP_ERR_RUNTIME, "internal: too many search passes");
     int tt = 0;
@@ -610,7 +683,7 @@ template <typename T>
 static int unpermute_enqueue(hipStream_t s, const SearchJob<T>& j, T* dst_d, long long* dst_i) {
     const long long n_elems = (long long)j.qidx.n * j.k;
     hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((n_elems + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       j.qidx.cell_of, j.qidx.rank, j.qidx.cell_start, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k);
+                       j.qidx.pos_of, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -628,8 +701,8 @@ static int validate_sizes(int64_t nq, int64_t nr, const char* qname, const char*
 
 struct Timer {
     pcu_hip_ctx* c; hipStream_t s; pcu_hip_stats* st;
-    void mark(int i) { if (st) (void)hipEventRecord(c->ev[i], s); }
-    float span(int i, int j) { float ms = 0; if (st) (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; }
+    void mark(int i) { if (st && c->time_phases) (void)hipEventRecord(c->ev[i], s); }
+    float span(int i, int j) { float ms = 0; if (st && c->time_phases) (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[j]); return ms; }
 };
 
 // Input staging: returns device pointer to the cloud (copying from host if needed).
@@ -654,6 +727,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
+    c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k);
     const double occ_q = 2.0;
     size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
@@ -672,7 +746,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (!on_dev) { if ((rc = aalloc(ar, &dd, (size_t)nq * k))) break; if ((rc = aalloc(ar, &di, (size_t)nq * k))) break; }
         SearchJob<T> job;
         if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
-        if ((rc = index_alloc(ar, job.qidx, nq, occ_q))) break;
+        if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/true))) break;
         ResultBlock* rb = nullptr;
         if ((rc = aalloc(ar, &rb, 1))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
@@ -681,8 +755,9 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if ((rc = index_build(job.ridx, dr, occ, s))) break;
-        if ((rc = index_build(job.qidx, dq, occ_q, s))) break;
+        if ((rc = index_build(job.ridx, dr, occ, s, true))) break;
+        if ((rc = index_build(job.qidx, dq, occ_q, s, true))) break;
+        index_large_pass<T>(job.ridx, &job.qidx, s);
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st))) break;
@@ -729,46 +804,47 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
 }
 template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
-                      bool squared, double occ, long long* ext_cxy, long long* ext_cyx, PairState<T>& P, Timer& tm,
+                      bool squared, double occ, bool want_pos_x, bool want_pos_y, PairState<T>& P, Timer& tm,
                       pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx) {
     P.two = two_sided;
     P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = tie_order_xy; P.yx.tie_order = tie_order_yx;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
-    if (index_alloc(ar, ix, nx, occ) || index_alloc(ar, iy, ny, occ)) return -1;
+    if (index_alloc(ar, ix, nx, occ, want_pos_x) || index_alloc(ar, iy, ny, occ, want_pos_y)) return -1;
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
     if (aalloc(ar, &P.rb, 1)) return -1;
     if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
     if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
-    (void)ext_cxy; (void)ext_cyx;
     if (aalloc(ar, &P.xy.out_i, (size_t)nx) || aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
+    HIP_TRY(hipMemsetAsync(P.rb, 0, sizeof(ResultBlock), s));       // both directions' counters (+ the epilogue's ticket) in one fill
     tm.mark(0);
     // fork: cloud y is indexed on the aux stream while cloud x is indexed on s
     // (measured: the passes are throughput-bound, so the overlap only buys ~3 %; off unless PCU_HIP_TWO_STREAMS is set)
     hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
-    if (index_build(ix, P.dx, occ, s) || index_build(iy, P.dy, occ, s2)) return -1;
+    if (index_build(ix, P.dx, occ, s, s2 == s) || index_build(iy, P.dy, occ, s2, s2 == s)) return -1;
+    if (s2 == s) index_large_pass<T>(ix, &iy, s);
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
     }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
-    if (search_enqueue(c, s, P.xy, st)) return -1;
-    if (two_sided && search_enqueue(c, s2, P.yx, st)) return -1;
+    if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
+    if (two_sided && search_enqueue(c, s2, P.yx, st, false)) return -1;
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[3], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[3], 0)); }   // join
     tm.mark(2);
     return 0;
 }
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
 template <typename T>
-static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host) {
-    HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false) {
+    if (!copied_by_kernel) HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     memcpy(host, c->h_pinned, sizeof(ResultBlock));
     int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
@@ -778,13 +854,18 @@ static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P
     return (r1 | r2) ? 1 : 0;
 }
 
+// Arg-max epilogue of one or both directions (+ copy of the result block to pinned host memory): one launch.
 template <typename T>
-static int argmax_enqueue(hipStream_t s, const SearchJob<T>& j, PairState<T>& P, int slot) {
-    const int n = j.qidx.n;
-    const int nb = std::min((n + kBlock - 1) / kBlock, kRedBlocks);
-    hipLaunchKernelGGL(k_argmax_partial<T>, dim3(nb), dim3(kBlock), 0, s, j.out_d, j.qidx.sorted, n, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks);
-    hipLaunchKernelGGL(k_argmax_final<T>, dim3(1), dim3(kBlock), 0, s, P.pv + slot * kRedBlocks, P.pi + slot * kRedBlocks, nb, j.out_i,
-                       P.res_v + slot, P.res_ij + 2 * slot);
+static int argmax_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, bool two_sided) {
+    auto side = [&](const SearchJob<T>& j) {
+        const int n = j.qidx.n;
+        return ArgmaxSide<T>{j.out_d, j.qidx.sorted, j.out_i, n, std::min((n + kBlock - 1) / kBlock, kRedBlocksFused)};
+    };
+    const ArgmaxSide<T> a = side(P.xy);
+    ArgmaxSide<T> b = a; b.n = 0; b.nb = 0;
+    if (two_sided) b = side(P.yx);
+    hipLaunchKernelGGL(k_argmax_pair<T>, dim3(a.nb + b.nb), dim3(kBlock), 0, s, a, b, P.pv, P.pi, P.res_v, P.res_ij,
+                       reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -797,19 +878,19 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
+    c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c}; Timer tm{c, s, st};
     int rc = 0;
     do {
         PairState<T> P;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, (long long*)nullptr, (long long*)nullptr, P, tm, st, two_sided, max_leaf, false, false))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, false, false, P, tm, st, two_sided, max_leaf, false, false))) break;
         ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
-            if (two_sided && (rc = argmax_enqueue(s, P.yx, P, 1))) break;
+            if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
             tm.mark(3);
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
             else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
         }
         if (rc) break;
@@ -831,8 +912,7 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
             }
             if (rc) break;
             if (redo) {
-                if ((rc = argmax_enqueue(s, P.xy, P, 0))) break;
-                if (two_sided && (rc = argmax_enqueue(s, P.yx, P, 1))) break;
+                if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
                 HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 memcpy(&host, c->h_pinned, sizeof host);
@@ -864,6 +944,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
+    c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c}; Timer tm{c, s, st};
@@ -876,25 +957,25 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
         // indices, or through a p != 2 norm of the difference vector; the p = 2 value is the tied distance itself.
         const bool tie_any = !(flags & PCU_HIP_NO_TIE_ORDER);
         const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, ext_xy, ext_yx, P, tm, st, true, max_leaf, tie_xy, tie_yx))) break;
+        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, out_cxy != nullptr, out_cyx != nullptr, P, tm, st, true, max_leaf, tie_xy, tie_yx))) break;
         // row-ordered correspondences: straight into the caller's device arrays, or via a staging buffer
         long long *dst_xy = ext_xy, *dst_yx = ext_yx;
         if (!on_dev && out_cxy && (rc = aalloc(ar, &dst_xy, (size_t)nx))) break;
         if (!on_dev && out_cyx && (rc = aalloc(ar, &dst_yx, (size_t)ny))) break;
         const int pc = pcode_of(p_norm);
         // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
-        const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocks), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocks);
+        const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
         ResultBlock host;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nbx), dim3(kBlock), 0, s, P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, pc, p_norm, P.pd);
-            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd, nbx, P.res_s + 0);
-            hipLaunchKernelGGL(k_pnorm_partial<T>, dim3(nby), dim3(kBlock), 0, s, P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, pc, p_norm, P.pd + kRedBlocks);
-            hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(kBlock), 0, s, P.pd + kRedBlocks, nby, P.res_s + 1);
-            HIP_TRY(hipGetLastError());
             if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
             if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
+            // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
+            const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx}, sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby};
+            hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
+                               reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned);
+            HIP_TRY(hipGetLastError());
             tm.mark(3);
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host); if (rc <= 0) break; rc = 0; }
+            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }
             else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
         }
         if (rc) break;
@@ -963,7 +1044,9 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
+    HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into it
     *out_ctx = c;
     return 0;
 }
@@ -978,6 +1061,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->tickets) (void)hipFree(c->tickets);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (auto& e : c->jev) if (e) (void)hipEventDestroy(e);

@@ -11,6 +11,7 @@
 namespace pcu {
 
 constexpr int kRedBlocks = 1024;
+constexpr int kRedBlocksFused = 128;     // per direction in the single-launch epilogues: every block takes one same-address ticket
 
 template <typename T>
 __device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long long i2) {
@@ -59,6 +60,64 @@ __global__ __launch_bounds__(kBlock) void k_argmax_final(const T* __restrict__ p
     }
 }
 
+// Hausdorff epilogue in one launch (both directions; nb = 0 for an absent second direction): per-block arg-max
+// partials, the last block to finish folds them, writes {value, i, j} per direction and copies the call's result
+// block to pinned host memory (see k_pnorm_pair).
+template <typename T>
+struct ArgmaxSide { const T* d; const Pt4<T>* qsorted; const long long* corr; int n; int nb; };
+
+template <typename T>
+__device__ __forceinline__ void block_argmax(T& v, long long& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
+        argmax_combine(v, idx, v2, i2);
+    }
+    __shared__ T sv[kBlock / 64]; __shared__ long long si[kBlock / 64];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);      // valid in thread 0
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, const ArgmaxSide<T> s1, T* pv, long long* pi,
+                                                        T* out_v, long long* out_ij, unsigned* ticket, const int* result_block, int* host_block) {
+    const bool second = (int)blockIdx.x >= s0.nb;
+    const ArgmaxSide<T>& sd = second ? s1 : s0;
+    const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
+    T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
+    for (int i = bid * kBlock + threadIdx.x; i < sd.n; i += sd.nb * kBlock)
+        argmax_combine(v, idx, sd.d[i], ((long long)sd.qsorted[i].idx << 32) | (long long)i);
+    block_argmax(v, idx);
+    __shared__ bool s_last;
+    if (threadIdx.x == 0) {
+        publish(&pv[blockIdx.x], v); publish(&pi[blockIdx.x], idx);
+        wait_stores();
+        s_last = take_ticket(ticket, gridDim.x);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int side = 0; side < 2; ++side) {
+        const int off = side ? s0.nb : 0, nb = side ? s1.nb : s0.nb;
+        if (nb == 0) continue;
+        T a = -Limits<T>::max_v; long long ai = 0x7fffffffffffffffll;
+        for (int i = threadIdx.x; i < nb; i += kBlock) argmax_combine(a, ai, peek(&pv[off + i]), peek(&pi[off + i]));
+        block_argmax(a, ai);
+        if (threadIdx.x == 0) {
+            out_v[side] = a; out_ij[2 * side] = ai >> 32;
+            out_ij[2 * side + 1] = (side ? s1.corr : s0.corr)[ai & 0xffffffffll];
+        }
+    }
+    if (threadIdx.x == 0) { *ticket = 0u; wait_stores(); }
+    __syncthreads();
+    if (host_block && threadIdx.x < 64) {
+        host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
+        __threadfence_system();
+    }
+}
+
 __device__ __forceinline__ double block_sum(double s) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -101,6 +160,61 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_partial(const Pt4<T>* __restri
     }
     double r = block_sum(s);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// Chamfer epilogue in one launch: blocks [0, nb0) reduce direction 0, blocks [nb0, nb0 + nb1) direction 1; the block
+// that finishes last (ticket) folds both directions' partials and copies the call's 256-byte result block (counters of
+// both searches + these sums) into pinned host memory, so the call needs no separate final-sum launches and no
+// device-to-host copy kernel behind them.
+template <typename T>
+struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; const T* d; int n; int nb; };
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, const PnormSide<T> s1, int pcode, double p, double* partial,
+                                                       double* out_sums, unsigned* ticket, const int* result_block, int* host_block) {
+    const bool second = (int)blockIdx.x >= s0.nb;
+    const PnormSide<T>& sd = second ? s1 : s0;
+    const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
+    double s = 0;
+    for (int i = bid * kBlock + threadIdx.x; i < sd.n; i += sd.nb * kBlock) {
+        T v;
+        if (pcode == P_TWO) {
+            v = sd.d[i];
+        } else {
+            const long long c = sd.corr[i];
+            const Pt4<T> q = sd.qsorted[i];
+            const T a = sd.tgt[3 * c] - q.x, b = sd.tgt[3 * c + 1] - q.y, e = sd.tgt[3 * c + 2] - q.z;
+            const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
+            if (pcode == P_ONE) v = (aa + ab) + ae;
+            else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; }
+            else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; }
+            else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));
+            else v = (T)pow((double)(T)((T)pow((double)aa, p) + (T)pow((double)ab, p)) + (double)(T)pow((double)ae, p), 1.0 / p);
+        }
+        s += (double)v;
+    }
+    const double r = block_sum(s);
+    __shared__ bool s_last;
+    if (threadIdx.x == 0) {
+        publish(&partial[blockIdx.x], r);
+        wait_stores();
+        s_last = take_ticket(ticket, gridDim.x);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double a0 = 0, a1 = 0;
+    for (int i = threadIdx.x; i < s0.nb; i += kBlock) a0 += peek(&partial[i]);
+    for (int i = threadIdx.x; i < s1.nb; i += kBlock) a1 += peek(&partial[s0.nb + i]);
+    __syncthreads();                         // block_sum's shared array is reused
+    const double r0 = block_sum(a0);
+    __syncthreads();
+    const double r1 = block_sum(a1);
+    if (threadIdx.x == 0) { out_sums[0] = r0; out_sums[1] = r1; *ticket = 0u; wait_stores(); }
+    __syncthreads();
+    if (host_block && threadIdx.x < 64) {
+        host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
+        __threadfence_system();
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_final(const double* __restrict__ partial, int nb, double* out) {

@@ -40,6 +40,8 @@ struct SearchArgs {
     const int* qcount_dev;          // nullable: device-side count for qlist passes
     int nq;                         // number of work items when qcount_dev is null
     int R;                          // search radius in cells
+    const int* qlist2; const int* qcount2_dev; int R2;   // wave-per-query passes: a second device-side list with its own radius,
+                                    // served by the same launch (work items = list 1 followed by list 2)
     unsigned n_ref;                 // number of dataset records; ref[n_ref] is the +inf sentinel record
     unsigned lane_max_cand;         // a lane whose 27 cells hold more candidates than this hands its query to the wave-per-query
                                     // pass (via the tie list) instead of scanning them serially: one heavy cell next to a query
@@ -110,6 +112,31 @@ template <typename T>
 __device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
     const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
     return ((dx * dx) + (dy * dy)) + (dz * dz);
+}
+
+// Row pruning. The 3x3 rows (oy, oz) around the query's cell are visited centre first; before a row is scanned its
+// lower bound is compared with the current k-th best: LB(oy, oz) = ((0) + (my*my)) + (mz*mz), where my / mz is the
+// (rounding-safe, see face_lower_bound) distance from the query to the slab of cells with cell_y < ccy (oy = -1) or
+// cell_y > ccy (oy = +1), 0 for oy = 0. Every computed d2 of a point in that row is >= LB, so a row with kth < LB
+// (strict: no tie can hide there either) is skipped by the lane. Typically 4-5 of the 9 rows survive. The lanes of a
+// wave skip different rows, so this saves few instructions -- it saves the *gathered bytes* (a skipped lane issues no
+// loads), and the L1 data path (64 B/clk/CU, ~1.7 KB gathered per query) is what bounds the lane-per-query kernels.
+__device__ constexpr int kRowOy[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+__device__ constexpr int kRowOz[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+template <typename T>
+__device__ __forceinline__ void row_lower_bounds(const GridParams<T>& g, const Pt4<T>& q, int ccy, int ccz, T (&lb)[9]) {
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    T my[3], mz[3];      // index 0: same row, 1: below, 2: above
+    my[0] = (T)0; mz[0] = (T)0;
+    { T m = q.y - face_below(g, 1, ccy); my[1] = m > (T)0 ? m * shrink : (T)0; }
+    { T m = face_above(g, 1, ccy) - q.y; my[2] = m > (T)0 ? m * shrink : (T)0; }
+    { T m = q.z - face_below(g, 2, ccz); mz[1] = m > (T)0 ? m * shrink : (T)0; }
+    { T m = face_above(g, 2, ccz) - q.z; mz[2] = m > (T)0 ? m * shrink : (T)0; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const T a = my[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], b = mz[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
+        lb[j] = (a * a) + (b * b);
+    }
 }
 
 // Offer one candidate to a lane's K best (ascending d2, registers). Ties are only *detected* here: an equal d2 that
@@ -231,8 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     unsigned rs[9], re[9];                 // rows centre-out: near rows first so the k-th best shrinks early
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const int oy = (j % 3 == 0) ? 0 : ((j % 3 == 1) ? -1 : 1), oz = (j / 3 == 0) ? 0 : ((j / 3 == 1) ? -1 : 1);
-        const int cy = ccy + oy, cz = ccz + oz;
+        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
         const bool ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
         const int lo = row_run_lo(Gx, grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz), x0, x1);
         rs[j] = a.cell_start[lo];
@@ -249,9 +275,11 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) total += re[j] - rs[j];
     const bool defer = total > a.lane_max_cand;
+    T rlb[9];
+    row_lower_bounds(g, q, ccy, ccz, rlb);
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        const unsigned e = defer ? rs[j] : re[j];
+        const unsigned e = (defer || bd[K - 1] < rlb[j]) ? rs[j] : re[j];
         for (unsigned p = rs[j]; p < e; p += kGroup) {
             Pt4<T> c[kGroup];
 #pragma unroll
@@ -265,6 +293,167 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     }
 
     finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Main pass for k = 1 (Chamfer / Hausdorff / k_nearest_neighbors(k=1)): same lane-per-query scan as k_search, on an
+// instruction diet. k_search<T,1> is VALU-issue bound (profiles/r01_pmc.txt: ~2.4k VALU instructions per wave, 4 cycles
+// each on a 16-lane SIMD = the kernel's whole duration), ~15 instructions per candidate. Here
+//   * a row is consumed in groups of 4 records from its first record on; the last group may run up to 3 records past
+//     the row's end. Those are real dataset points of the cells that follow in snake order (or the +inf sentinels behind
+//     the last record), so offering them is harmless and no slot needs masking or a select on its address. (At a grid
+//     border the records that follow can belong to another row of the same 27 cells: a point seen twice looks like a
+//     tie with itself and merely sends the query through the tie pass.)
+//   * the (x,y) differences, squares of a record go through the packed-fp32 pipe (v_pk_add_f32 / v_pk_mul_f32: IEEE
+//     add and mul, no FMA -- bit-identical to the scalar sequence);
+//   * only the running minimum d2 and the *group* it came from are tracked (v_min3 + one compare + two selects per 4
+//     candidates instead of a compare and two selects per candidate); the winning record is identified afterwards by
+//     re-evaluating that one group. An equal minimum met in another group, or twice inside the winning group, flags a
+//     possible tie exactly as before (re-resolved by the wave-per-query pass under the total order).
+// Only for open indexes (closed sub-box levels have no sentinel behind their last record).
+template <typename T> struct K1Group { static constexpr int n = 4; };     // (8 measured slower: more bytes gathered past the row ends)
+__device__ __forceinline__ float min2(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double min2(double a, double b) { return __builtin_fmin(a, b); }
+struct __attribute__((packed, aligned(4))) CellStart4 { unsigned v[4]; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dist2_k1(const Pt4<float>& q, const Pt4<float>& c) {
+    const f32x2 qxy = {q.x, q.y}, cxy = {c.x, c.y};
+    const f32x2 d = qxy - cxy;
+    const f32x2 dd = d * d;
+    const float dz = q.z - c.z;
+    return (dd.x + dd.y) + (dz * dz);
+}
+__device__ __forceinline__ double dist2_k1(const Pt4<double>& q, const Pt4<double>& c) { return dist2(q, c); }
+__device__ __forceinline__ float min4(float a, float b, float c, float d) { return __builtin_fminf(__builtin_fminf(__builtin_fminf(a, b), c), d); }
+__device__ __forceinline__ double min4(double a, double b, double c, double d) { return __builtin_fmin(__builtin_fmin(a, b), __builtin_fmin(c, d)); }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
+    const int per = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);       // XCD-aware block order, see k_search
+    const int t = vb * kBlock + threadIdx.x;
+    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    if (t >= nq) return;
+    const int qpos = a.qlist ? a.qlist[t] : t;
+    const Pt4<T> q = a.qsorted[qpos];
+    const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
+    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
+    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
+    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
+
+    // Row tables: ONE 16-byte load per row fetches the starts of the run's (up to) three cells and its end,
+    // cell_start[lo .. lo+3] (only dword-aligned; entries past the run are loaded but not used), instead of two 4-byte
+    // loads for the run's ends: half the index loads, and the inner cell boundaries come for free (cell pruning below).
+    const int len = x1 - x0 + 1;                      // cells per row run: 3, 2 at a grid border (1 if Gx == 1)
+    unsigned cs0[9], cs1[9], cs2[9], cs3[9];
+    bool odd[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
+        const bool ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
+        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
+        const CellStart4 v = *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
+        odd[j] = row & 1;
+        cs0[j] = v.v[0];
+        cs1[j] = ok ? v.v[1] : v.v[0];
+        cs2[j] = ok ? v.v[2] : v.v[0];
+        cs3[j] = ok ? v.v[3] : v.v[0];
+    }
+    unsigned total = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) total += (len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j])) - cs0[j];
+    const bool defer = total > a.lane_max_cand;
+
+    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
+    constexpr int kG = K1Group<T>::n;       // records per group
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    T best = Limits<T>::max_v;
+    unsigned boff = 0xffffffffu;            // byte offset of the group that holds the running minimum
+    unsigned toff = 0xffffffffu;            // ... of the last group that repeated it
+    bool tie = false, tie2 = false;         // running minimum met again in another group / more than once
+    // Pruning, per lane, against the running minimum (strict '<': no tie can hide in what is skipped either):
+    //   rows   LB = (my*my) + (mz*mz)                 my / mz: rounding-safe distance to the slab of the row (0: own)
+    //   cells  LB = ((mx*mx) + (my*my)) + (mz*mz)     for the run's outer cells ccx-1 / ccx+1; the cut run stays contiguous
+    T rlb[9];
+    row_lower_bounds(g, q, ccy, ccz, rlb);
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
+    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
+    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
+    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;           // the run has a cell left / right of the query's
+    T my2[3], mz2[3];
+    {
+        T m;
+        my2[0] = (T)0; mz2[0] = (T)0;
+        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
+        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
+        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
+        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const bool any = !defer && !(best < rlb[j]);
+        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
+        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
+        // even rows run in +x (first cell in memory = x0), odd rows in -x (first cell = x1)
+        const bool cut_first = odd[j] ? cut_hi : cut_lo, cut_last = odd[j] ? cut_lo : cut_hi;
+        const unsigned s_run = cut_first ? cs1[j] : cs0[j];
+        const unsigned e_full = len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j]);
+        const unsigned e_cut = len == 3 ? cs2[j] : (len == 2 ? cs1[j] : cs0[j]);
+        const unsigned e_run = cut_last ? e_cut : e_full;
+        const unsigned o0 = s_run * kRec;
+        const unsigned o1 = any ? e_run * kRec : o0;
+        for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
+            const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
+            T m;
+            if (kG == 8) {
+                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7];
+                m = min2(min4(dist2_k1(q, c0), dist2_k1(q, c1), dist2_k1(q, c2), dist2_k1(q, c3)),
+                         min4(dist2_k1(q, c4), dist2_k1(q, c5), dist2_k1(q, c6), dist2_k1(q, c7)));
+            } else {
+                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                m = min4(dist2_k1(q, c0), dist2_k1(q, c1), dist2_k1(q, c2), dist2_k1(q, c3));
+            }
+            const bool eq = m == best, lt = m < best;
+            tie2 = !lt && (tie2 || (tie && eq));
+            tie = !lt && (tie || eq);
+            toff = eq ? off : toff;
+            best = lt ? m : best;
+            boff = lt ? off : boff;
+        }
+    }
+    T bd[1] = {best};
+    int bi[1] = {0x7fffffff};
+    if (boff != 0xffffffffu) {
+        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)boff);
+        int hits = 0;
+#pragma unroll
+        for (int u = kG - 1; u >= 0; --u) {
+            const Pt4<T> cu = c[u];
+            const bool eq = dist2_k1(q, cu) == best;
+            hits += eq ? 1 : 0;
+            bi[0] = eq ? (int)cu.idx : bi[0];
+        }
+        if (hits > 1) { tie = true; tie2 = true; }
+    }
+    if (tie && !tie2) {
+        // The minimum was met exactly once more, in group `toff`. At a grid border the records behind a row's end can
+        // belong to another row of the same 27 cells, so this may be the winner itself seen twice: not a tie.
+        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)toff);
+        int hits = 0, id = 0x7fffffff;
+#pragma unroll
+        for (int u = kG - 1; u >= 0; --u) {
+            const Pt4<T> cu = c[u];
+            const bool eq = dist2_k1(q, cu) == best;
+            hits += eq ? 1 : 0;
+            id = eq ? (int)cu.idx : id;
+        }
+        if (hits == 1 && id == bi[0]) tie = false;
+    }
+    finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -411,13 +600,16 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * kBlock) >> 6;
-    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    const int nq1 = a.qcount_dev ? *a.qcount_dev : a.nq;
+    const int nq = nq1 + (a.qlist2 ? *a.qcount2_dev : 0);
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (wave == 0 && lane == 0) *a.skew_flag = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int R = a.R, kreq = a.kreq;
+    const int kreq = a.kreq;
     for (int w = wave; w < nq; w += nwaves) {
-        const int qpos = a.qlist ? a.qlist[w] : w;
+        const bool second = w >= nq1;
+        const int R = second ? a.R2 : a.R;
+        const int qpos = second ? a.qlist2[w - nq1] : (a.qlist ? a.qlist[w] : w);
         const Pt4<T> q = a.qsorted[qpos];
         const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
         const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
@@ -432,20 +624,30 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
             const int cz = z0 + r / ny, cy = y0 + r % ny;
             const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
             const unsigned s = a.cell_start[lo], e = a.cell_start[lo + (x1 - x0 + 1)];
-            for (unsigned p = s; p < e; ++p) {
-                const Pt4<T> c = a.ref[p];
-                const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
-                const int id = (int)c.idx;
-                if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
+            // small K: four candidates per trip, their loads issued together (the pass is latency-bound: a lane's
+            // row is a chain of dependent-free but serially awaited loads otherwise); slots past the row's end are
+            // killed (+inf / NaN d2 never enters the list)
+            constexpr int kU = K <= 8 ? 4 : 1;
+            for (unsigned p = s; p < e; p += kU) {
+                Pt4<T> cc[kU];
 #pragma unroll
-                    for (int i = K - 1; i > 0; --i) {
-                        const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
-                        const bool gi = lex_less(d, id, bd[i], bi[i]);
-                        bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
-                        bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, e - 1u)];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const Pt4<T>& c = cc[u];
+                    const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                    const T d = kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= e);
+                    const int id = (int)c.idx;
+                    if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
+#pragma unroll
+                        for (int i = K - 1; i > 0; --i) {
+                            const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
+                            const bool gi = lex_less(d, id, bd[i], bi[i]);
+                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                        }
+                        if (K == 1 || lex_less(d, id, bd[0], bi[0])) { bd[0] = d; bi[0] = id; }
                     }
-                    if (K == 1 || lex_less(d, id, bd[0], bi[0])) { bd[0] = d; bi[0] = id; }
                 }
             }
         }
@@ -493,20 +695,19 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
     }
 }
 
-// Restores the caller's row order: out[i, :] = res[pos(i), :], pos(i) = cell_start[cell_of[i]] + rank[i] (the slot
-// the index build gave row i). One thread per output element: reads of cell_of/rank and writes of out are
-// coalesced; the cell-ordered result rows are gathered (they were just written and are L2/MALL resident). The main
-// pass therefore writes full coalesced rows instead of scattering 4/8-byte values over the row-ordered arrays
-// (which cost ~5x the algorithmic write traffic, profiles/r01_pmc.txt).
+// Restores the caller's row order: out[i, :] = res[pos_of[i], :], pos_of[i] = the slot the index build gave row i. One
+// thread per output element: reads of pos_of and writes of out are coalesced; the cell-ordered result rows are gathered
+// (they were just written and are L2/MALL resident). The main pass therefore writes full coalesced rows instead of
+// scattering 4/8-byte values over the row-ordered arrays (which cost ~5x the algorithmic write traffic,
+// profiles/r01_pmc.txt).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict__ cell_of, const unsigned* __restrict__ rank,
-                                                      const unsigned* __restrict__ cell_start, const T* __restrict__ res_d,
+__global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict__ pos_of, const T* __restrict__ res_d,
                                                       const long long* __restrict__ res_i, T* __restrict__ out_d,
                                                       long long* __restrict__ out_i, long long n_elems, int k) {
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_elems) return;
     const long long i = t / k; const int j = (int)(t - i * k);
-    const size_t src = (size_t)(cell_start[cell_of[i]] + rank[i]) * (size_t)k + j;
+    const size_t src = (size_t)pos_of[i] * (size_t)k + j;
     if (out_d) out_d[t] = res_d[src];
     if (out_i) out_i[t] = res_i[src];
 }

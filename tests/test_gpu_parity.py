@@ -317,3 +317,26 @@ def test_unbalanced_clouds_refit_path(pcu, oracle_kind, dtype):
     ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True)
     ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=oracle_kind)
     assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dense_slab_bucketed_index(pcu, oracle_kind, dtype):
+    """A dense slab inside a uniform cloud: some buckets of the bucketed index build hold far more points than one
+    workgroup sorts (the per-cell-atomic route for large buckets), while the grid as a whole stays below the refit
+    threshold, so the searches run on that index. Rows are restored through the build's row -> slot map."""
+    rng = np.random.default_rng(21)
+    def make(nu, nb):
+        slab = rng.random((nb, 3)) * [0.3, 0.3, 0.05] + [0.3, 0.3, 0.5]
+        return np.concatenate([rng.random((nu, 3)), slab]).astype(dtype)
+    r, q = make(150000, 50000), make(120000, 40000)
+    for k in (1, 4):
+        d, c = pcu.k_nearest_neighbors(q, r, k)
+        st = pcu.last_stats()
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+        _assert_knn(pcu, d, c, d0, c0)
+        assert st["n_grid_builds"] == 2, st             # no refit: the first index served the whole search
+    ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch) - float(ch0)) <= (1e-4 if dtype == np.float32 else 1e-6) * float(ch0)
+    assert pcu.hausdorff_distance(q, r, return_index=True) == oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
