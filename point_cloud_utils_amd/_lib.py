@@ -5,7 +5,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcu_hip.so")
+LIB_PATH = os.environ.get("PCU_HIP_LIBRARY") or os.path.join(_HERE, "libpcu_hip.so")    # override: A/B builds of the same ABI
 
 PTRS_ON_DEVICE = 1
 SQUARED = 2

@@ -14,6 +14,10 @@
 #pragma once
 #include "pcu_types.h"
 
+#ifndef PCU_SORT_THREADS
+#define PCU_SORT_THREADS 512      // workgroup size of k_bucket_sort (tuning knob; 1024 measured slower)
+#endif
+
 namespace pcu {
 
 constexpr int kBlock = 256;
@@ -333,7 +337,7 @@ constexpr int kBkPts = 4;                           // points per thread of the 
 constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
 constexpr int kBkMaxBuckets = 4096;
 constexpr int kBkMaxCellsPerBucket = 4096;
-constexpr int kSortThreads = 1024;
+constexpr int kSortThreads = PCU_SORT_THREADS;
 constexpr int kSortIters = 16;
 constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 16384 points
 

@@ -315,7 +315,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     const int tb = use_gather ? kBlock : 64;
     dim3 grid((((nwork + tb - 1) / tb) + 7) / 8 * 8), block(tb);
     if (K == 1 && use_gather && use_k1 && open_index) {        // k = 1 on an open index: the group-wise kernel
-        hipLaunchKernelGGL((k_search1<T>), grid, block, 0, s, a);
+        static const bool flat = [] { const char* e = getenv("PCU_HIP_K1"); return !(e && strcmp(e, "rows") == 0); }();
+        if (flat) hipLaunchKernelGGL((k_search1<T, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_search1<T, false>), grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -176,7 +176,12 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
     const PnormSide<T>& sd = second ? s1 : s0;
     const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
     double s = 0;
-    for (int i = bid * kBlock + threadIdx.x; i < sd.n; i += sd.nb * kBlock) {
+    const int n_vec = pcode == P_TWO ? (sd.n & ~3) : 0;       // p = 2: the distances themselves, four per 16/32-byte load
+    for (int i = 4 * (bid * kBlock + (int)threadIdx.x); i < n_vec; i += 4 * sd.nb * kBlock) {
+        const T v0 = sd.d[i], v1 = sd.d[i + 1], v2 = sd.d[i + 2], v3 = sd.d[i + 3];
+        s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (int i = n_vec + bid * kBlock + (int)threadIdx.x; i < sd.n; i += sd.nb * kBlock) {
         T v;
         if (pcode == P_TWO) {
             v = sd.d[i];

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 //     re-evaluating that one group. An equal minimum met in another group, or twice inside the winning group, flags a
 //     possible tie exactly as before (re-resolved by the wave-per-query pass under the total order).
 // Only for open indexes (closed sub-box levels have no sentinel behind their last record).
-template <typename T> struct K1Group { static constexpr int n = 4; };     // (8 measured slower: more bytes gathered past the row ends)
+template <typename T> struct K1Group { static constexpr int n = 4; };     // records per group (8 measured slower: more bytes gathered past the row ends)
 __device__ __forceinline__ float min2(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ double min2(double a, double b) { return __builtin_fmin(a, b); }
 struct __attribute__((packed, aligned(4))) CellStart4 { unsigned v[4]; };
@@ -327,7 +327,18 @@ __device__ __forceinline__ double dist2_k1(const Pt4<double>& q, const Pt4<doubl
 __device__ __forceinline__ float min4(float a, float b, float c, float d) { return __builtin_fminf(__builtin_fminf(__builtin_fminf(a, b), c), d); }
 __device__ __forceinline__ double min4(double a, double b, double c, double d) { return __builtin_fmin(__builtin_fmin(a, b), __builtin_fmin(c, d)); }
 
-template <typename T>
+// FLAT variant (default): after the centre row has given a first estimate, the surviving cut runs of the other eight rows
+// are written to a per-lane list in LDS ({byte offset, record count, row bound as a round-down bf16}: 8 bytes each) and
+// consumed by ONE loop per lane, with the next group's four loads issued before the current group is evaluated. The
+// lanes of a wave then walk their own lists in lock step (a wave runs max-over-lanes of the TOTAL group count instead of
+// the sum over rows of per-row maxima) and every wait on memory covers two groups. Row pruning stays adaptive (the bound
+// is re-checked, against a minimum that may be one group stale -- still a valid bound -- when a lane moves to its next
+// run); the cell cuts are those decided after the centre row.
+__device__ __forceinline__ unsigned lb_pack(float lb) { return __float_as_uint(lb) >> 16; }                  // truncation rounds a value >= 0 down
+__device__ __forceinline__ unsigned lb_pack(double lb) { const double v = lb * (1.0 - 1e-6); return __float_as_uint((float)(v < 1e38 ? v : 1e38)) >> 16; }
+template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { return (T)__uint_as_float(b << 16); }
+
+template <typename T, bool FLAT>
 __global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
     const int per = (int)(gridDim.x >> 3);
     const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);       // XCD-aware block order, see k_search
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
     unsigned total = 0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) total += (len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j])) - cs0[j];
-    const bool defer = total > a.lane_max_cand;
+    const bool defer = total > (a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u);      // (FLAT packs a run's record count into 16 bits)
 
     constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
     constexpr int kG = K1Group<T>::n;       // records per group
@@ -393,6 +404,81 @@ __global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
         m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
         m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
     }
+    // one group of kG records at byte offset `off`: minimum d2, then the running minimum / tie bookkeeping
+#define PCU_K1_EVAL(C0, C1, C2, C3, OFF)                                                                     \
+    {                                                                                                        \
+        const T m_ = min4(dist2_k1(q, C0), dist2_k1(q, C1), dist2_k1(q, C2), dist2_k1(q, C3));             \
+        const bool eq_ = m_ == best, lt_ = m_ < best;                                                        \
+        tie2 = !lt_ && (tie2 || (tie && eq_));                                                               \
+        tie = !lt_ && (tie || eq_);                                                                          \
+        toff = eq_ ? (OFF) : toff;                                                                           \
+        best = lt_ ? m_ : best;                                                                              \
+        boff = lt_ ? (OFF) : boff;                                                                           \
+    }
+    if (FLAT) {
+        __shared__ uint2 s_rng[8][kBlock];
+        const int tid = threadIdx.x;
+        // centre row: whole run
+        {
+            const unsigned o0 = cs0[0] * kRec;
+            const unsigned o1 = defer ? o0 : (len == 3 ? cs3[0] : (len == 2 ? cs2[0] : cs1[0])) * kRec;
+            for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
+                const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
+                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+                PCU_K1_EVAL(c0, c1, c2, c3, off)
+            }
+        }
+        // the other rows: cut runs that survive the centre row's minimum -> this lane's list
+        int n = 0;
+#pragma unroll
+        for (int j = 1; j < 9; ++j) {
+            const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
+            const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
+            const bool cut_first = odd[j] ? cut_hi : cut_lo, cut_last = odd[j] ? cut_lo : cut_hi;
+            const unsigned s_run = cut_first ? cs1[j] : cs0[j];
+            const unsigned e_full = len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j]);
+            const unsigned e_cut = len == 3 ? cs2[j] : (len == 2 ? cs1[j] : cs0[j]);
+            const unsigned e_run = cut_last ? e_cut : e_full;
+            if (!defer && !(best < rlb[j]) && e_run > s_run) {
+                s_rng[n][tid] = make_uint2(s_run * kRec, ((e_run - s_run) << 16) | lb_pack(rlb[j]));
+                ++n;
+            }
+        }
+        int r = 0;
+        unsigned off = 0, end = 0;
+        bool live = false;
+        auto next_run = [&]() {
+            live = false;
+            while (r < n) {
+                const uint2 e = s_rng[r][tid];
+                ++r;
+                if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + (e.y >> 16) * kRec; live = true; break; }
+            }
+        };
+        next_run();
+        // Ping-pong: A is evaluated while B's four loads are in flight, and vice versa. The loads are unconditional
+        // straight-line code (a lane that has just run out of work fetches the +inf sentinel records once): loads issued
+        // under a branch would make the compiler wait for them at the join, i.e. before the older group is evaluated.
+        const unsigned sent_off = a.n_ref * kRec;
+        Pt4<T> a0, a1, a2, a3, b0, b1, b2, b3;
+        if (live) {
+            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
+            for (;;) {
+                unsigned coff = off;
+                off += (unsigned)kG * kRec;
+                if (off >= end) next_run();
+                { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); b0 = c[0]; b1 = c[1]; b2 = c[2]; b3 = c[3]; }
+                PCU_K1_EVAL(a0, a1, a2, a3, coff)
+                if (!live) break;
+                coff = off;
+                off += (unsigned)kG * kRec;
+                if (off >= end) next_run();
+                { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
+                PCU_K1_EVAL(b0, b1, b2, b3, coff)
+                if (!live) break;
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const bool any = !defer && !(best < rlb[j]);
@@ -408,23 +494,11 @@ __global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
         const unsigned o1 = any ? e_run * kRec : o0;
         for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
             const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
-            T m;
-            if (kG == 8) {
-                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], c7 = c[7];
-                m = min2(min4(dist2_k1(q, c0), dist2_k1(q, c1), dist2_k1(q, c2), dist2_k1(q, c3)),
-                         min4(dist2_k1(q, c4), dist2_k1(q, c5), dist2_k1(q, c6), dist2_k1(q, c7)));
-            } else {
-                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-                m = min4(dist2_k1(q, c0), dist2_k1(q, c1), dist2_k1(q, c2), dist2_k1(q, c3));
-            }
-            const bool eq = m == best, lt = m < best;
-            tie2 = !lt && (tie2 || (tie && eq));
-            tie = !lt && (tie || eq);
-            toff = eq ? off : toff;
-            best = lt ? m : best;
-            boff = lt ? off : boff;
+            const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            PCU_K1_EVAL(c0, c1, c2, c3, off)
         }
     }
+#undef PCU_K1_EVAL
     T bd[1] = {best};
     int bi[1] = {0x7fffffff};
     if (boff != 0xffffffffu) {
