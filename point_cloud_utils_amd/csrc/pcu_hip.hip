@@ -315,8 +315,12 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     const int tb = use_gather ? kBlock : 64;
     dim3 grid((((nwork + tb - 1) / tb) + 7) / 8 * 8), block(tb);
     if (K == 1 && use_gather && use_k1 && open_index) {        // k = 1 on an open index: the group-wise kernel
-        static const bool flat = [] { const char* e = getenv("PCU_HIP_K1"); return !(e && strcmp(e, "rows") == 0); }();
-        if (flat) hipLaunchKernelGGL((k_search1<T, true>), grid, block, 0, s, a);
+        static const int variant = [] { const char* e = getenv("PCU_HIP_K1"); return !e ? 0 : (strcmp(e, "early") == 0 ? 1 : (strcmp(e, "flat93") == 0 ? 2 : (strcmp(e, "rows") == 0 ? 3 : 0))); }();
+        static const bool w8 = getenv("PCU_HIP_K1_W8") != nullptr;
+        if (variant == 0 && w8 && sizeof(T) == 4) hipLaunchKernelGGL((k_search1_flat<T, false, 8>), grid, block, 0, s, a);
+        else if (variant == 0) hipLaunchKernelGGL((k_search1_flat<T, false, 4>), grid, block, 0, s, a);
+        else if (variant == 1) hipLaunchKernelGGL((k_search1_flat<T, true, 4>), grid, block, 0, s, a);
+        else if (variant == 2) hipLaunchKernelGGL((k_search1<T, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_search1<T, false>), grid, block, 0, s, a);
         HIP_TRY(hipGetLastError());
         return 0;

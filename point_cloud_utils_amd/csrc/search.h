@@ -530,6 +530,173 @@ __global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
     finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
 
+// k = 1 main pass, flattened (the default). Same arithmetic, pruning rules and tie bookkeeping as k_search1<T, true>, laid
+// out for registers: the centre row's table is loaded and scanned first; only then are the other eight rows' tables
+// fetched (EARLY = false; one more dependent wait per wave, but their 32 registers are not live during the centre scan,
+// which brings the kernel from 93 to <= 64 VGPRs, i.e. from 5 to 8 waves per SIMD) or, with EARLY = true, right away.
+template <typename T, bool EARLY, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs<T> a) {
+    __shared__ uint2 s_rng[8][kBlock];
+    const int per = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);       // XCD-aware block order, see k_search
+    const int t = vb * kBlock + threadIdx.x;
+    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    if (t >= nq) return;
+    const int tid = threadIdx.x;
+    const int qpos = a.qlist ? a.qlist[t] : t;
+    const Pt4<T> q = a.qsorted[qpos];
+    const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
+    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
+    const int len = x1 - x0 + 1;                      // cells per row run: 3, 2 at a grid border (1 if Gx == 1)
+    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
+    constexpr int kG = K1Group<T>::n;
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const unsigned cand_cap = a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u;     // a run's record count is packed into 16 bits
+    T best = Limits<T>::max_v;
+    unsigned boff = 0xffffffffu, toff = 0xffffffffu;
+    bool tie = false, tie2 = false;
+#define PCU_K1_EVAL(C0, C1, C2, C3, OFF)                                                                     \
+    {                                                                                                        \
+        const T m_ = min4(dist2_k1(q, C0), dist2_k1(q, C1), dist2_k1(q, C2), dist2_k1(q, C3));             \
+        const bool eq_ = m_ == best, lt_ = m_ < best;                                                        \
+        tie2 = !lt_ && (tie2 || (tie && eq_));                                                               \
+        tie = !lt_ && (tie || eq_);                                                                          \
+        toff = eq_ ? (OFF) : toff;                                                                           \
+        best = lt_ ? m_ : best;                                                                              \
+        boff = lt_ ? (OFF) : boff;                                                                           \
+    }
+    auto row_table = [&](int j, bool& ok, bool& odd) {
+        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
+        ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
+        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
+        odd = row & 1;
+        return *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
+    };
+    bool okj[9], oddj[9];
+    CellStart4 tb[9];
+    tb[0] = row_table(0, okj[0], oddj[0]);
+    if (EARLY) {
+#pragma unroll
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+    }
+    // ---- centre row: whole run
+    const unsigned cnt0 = (len == 3 ? tb[0].v[3] : (len == 2 ? tb[0].v[2] : tb[0].v[1])) - tb[0].v[0];
+    bool defer = cnt0 > cand_cap;
+    {
+        const unsigned o0 = tb[0].v[0] * kRec;
+        const unsigned o1 = defer ? o0 : o0 + cnt0 * kRec;
+        for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
+            const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
+            const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            PCU_K1_EVAL(c0, c1, c2, c3, off)
+        }
+    }
+    // ---- the other rows: cut runs that survive the centre row's minimum -> this lane's list
+    if (!EARLY) {
+#pragma unroll
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+    }
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
+    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
+    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
+    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;
+    T my2[3], mz2[3];
+    {
+        T m;
+        my2[0] = (T)0; mz2[0] = (T)0;
+        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
+        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
+        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
+        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
+    }
+    unsigned total = cnt0;
+#pragma unroll
+    for (int j = 1; j < 9; ++j) total += okj[j] ? (len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1])) - tb[j].v[0] : 0u;
+    defer = defer || total > cand_cap;
+    int n = 0;
+#pragma unroll
+    for (int j = 1; j < 9; ++j) {
+        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
+        const T rlb = ry + rz;                                      // = ((0) + (my*my)) + (mz*mz), see row_lower_bounds
+        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
+        const bool cut_first = oddj[j] ? cut_hi : cut_lo, cut_last = oddj[j] ? cut_lo : cut_hi;
+        const unsigned s_run = cut_first ? tb[j].v[1] : tb[j].v[0];
+        const unsigned e_full = len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1]);
+        const unsigned e_cut = len == 3 ? tb[j].v[2] : (len == 2 ? tb[j].v[1] : tb[j].v[0]);
+        const unsigned e_run = cut_last ? e_cut : e_full;
+        if (okj[j] && !defer && !(best < rlb) && e_run > s_run) {
+            s_rng[n][tid] = make_uint2(s_run * kRec, ((e_run - s_run) << 16) | lb_pack(rlb));
+            ++n;
+        }
+    }
+    int r = 0;
+    unsigned off = 0, end = 0;
+    bool live = false;
+    auto next_run = [&]() {
+        live = false;
+        while (r < n) {
+            const uint2 e = s_rng[r][tid];
+            ++r;
+            if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + (e.y >> 16) * kRec; live = true; break; }
+        }
+    };
+    next_run();
+    const unsigned sent_off = a.n_ref * kRec;
+    if (live) {     // ping-pong, unconditional loads: see k_search1<T, true>
+        Pt4<T> a0, a1, a2, a3, b0, b1, b2, b3;
+        { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
+        for (;;) {
+            unsigned coff = off;
+            off += (unsigned)kG * kRec;
+            if (off >= end) next_run();
+            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); b0 = c[0]; b1 = c[1]; b2 = c[2]; b3 = c[3]; }
+            PCU_K1_EVAL(a0, a1, a2, a3, coff)
+            if (!live) break;
+            coff = off;
+            off += (unsigned)kG * kRec;
+            if (off >= end) next_run();
+            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
+            PCU_K1_EVAL(b0, b1, b2, b3, coff)
+            if (!live) break;
+        }
+    }
+#undef PCU_K1_EVAL
+    // ---- which record of the winning group it was; ties (see k_search1)
+    T bd[1] = {best};
+    int bi[1] = {0x7fffffff};
+    if (boff != 0xffffffffu) {
+        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)boff);
+        int hits = 0;
+#pragma unroll
+        for (int u = kG - 1; u >= 0; --u) {
+            const Pt4<T> cu = c[u];
+            const bool eq = dist2_k1(q, cu) == best;
+            hits += eq ? 1 : 0;
+            bi[0] = eq ? (int)cu.idx : bi[0];
+        }
+        if (hits > 1) { tie = true; tie2 = true; }
+    }
+    if (tie && !tie2) {
+        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)toff);
+        int hits = 0, id = 0x7fffffff;
+#pragma unroll
+        for (int u = kG - 1; u >= 0; --u) {
+            const Pt4<T> cu = c[u];
+            const bool eq = dist2_k1(q, cu) == best;
+            hits += eq ? 1 : 0;
+            id = eq ? (int)cu.idx : id;
+        }
+        if (hits == 1 && id == bi[0]) tie = false;
+    }
+    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
+    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
+    finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
+}
+
 // -------------------------------------------------------------------------------------------------------
 // Main pass, LDS-tiled (the default): ONE WAVE = 64 consecutive queries of the cell-ordered query cloud, i.e. a
 // compact snake of query cells. The wave takes the bounding box of its lanes' dataset cells (+1 cell), and for

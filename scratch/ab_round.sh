@@ -3,11 +3,12 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/ab_pytest.txt
-for v in default k1rows nok1; do
+for v in default w8 early flat93; do
   case $v in
     default) E="" ;;
-    k1rows) E="PCU_HIP_K1=rows" ;;
-    nok1) E="PCU_HIP_NO_K1=1" ;;
+    w8) E="PCU_HIP_K1_W8=1" ;;
+    early) E="PCU_HIP_K1=early" ;;
+    flat93) E="PCU_HIP_K1=flat93" ;;
   esac
   echo "== $v" >> gpurun_out/ab_bench.txt
   env $E timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline >> gpurun_out/ab_bench.txt 2>&1
