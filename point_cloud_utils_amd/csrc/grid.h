@@ -65,10 +65,27 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ pts, int n, T* partial,
                                                          unsigned* __restrict__ counts, int n_counts,
                                                          unsigned* ticket = nullptr, GridParams<T>* gp = nullptr, double occupancy = 0,
-                                                         int max_cells = 0, Pt4<T>* sentinel = nullptr) {
+                                                         int max_cells = 0, Pt4<T>* sentinel = nullptr,
+                                                         unsigned* __restrict__ zero2 = nullptr, int n_zero2 = 0) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    // four points = 12 consecutive scalars = three 16-byte (f32) loads per trip, all in flight together; a plain
+    // point-per-trip loop waits for memory 15 times per thread at n = 1M
+    struct __attribute__((packed, aligned(4))) Vec4 { T v[4]; };
+    const int n4 = n >> 2;
+    const int gtid = blockIdx.x * kBlock + threadIdx.x, gstride = gridDim.x * kBlock;
+    for (int gi = gtid; gi < n4; gi += gstride) {
+        const Vec4* p = reinterpret_cast<const Vec4*>(pts + 12 * (size_t)gi);
+        const Vec4 a = p[0], b = p[1], c = p[2];
+        const T v[12] = {a.v[0], a.v[1], a.v[2], a.v[3], b.v[0], b.v[1], b.v[2], b.v[3], c.v[0], c.v[1], c.v[2], c.v[3]};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            lo[k % 3] = v[k] < lo[k % 3] ? v[k] : lo[k % 3];
+            hi[k % 3] = v[k] > hi[k % 3] ? v[k] : hi[k % 3];
+        }
+    }
+    if (gtid < (n & 3)) {
+        const int i = (n4 << 2) + gtid;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             T v = pts[3 * (size_t)i + j];
@@ -76,7 +93,13 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ p
             hi[j] = v > hi[j] ? v : hi[j];
         }
     }
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_counts; i += gridDim.x * kBlock) counts[i] = 0u;
+    {   // zero-fill (16-byte stores; `counts` is 256-byte aligned arena memory)
+        uint4* c4 = reinterpret_cast<uint4*>(counts);
+        const int m4 = n_counts >> 2;
+        for (int i = gtid; i < m4; i += gstride) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (gtid < (n_counts & 3)) counts[(m4 << 2) + gtid] = 0u;
+        for (int i = gtid; i < n_zero2; i += gstride) zero2[i] = 0u;
+    }
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -375,12 +398,16 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const T* __restrict
     for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * kBkBlockPts;
+    T px[kBkPts], py[kBkPts], pz[kBkPts];            // all loads first (clamped index, no branch): one wait instead of kBkPts
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
-        const int i = base + j * kBkThreads + (int)threadIdx.x;
-        const bool valid = i < n;
-        unsigned b = 0;
-        if (valid) b = cell_linear(g, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]) >> shift;
+        const int i = min(base + j * kBkThreads + (int)threadIdx.x, n - 1);
+        px[j] = pts[3 * (size_t)i]; py[j] = pts[3 * (size_t)i + 1]; pz[j] = pts[3 * (size_t)i + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const bool valid = base + j * kBkThreads + (int)threadIdx.x < n;
+        const unsigned b = cell_linear(g, px[j], py[j], pz[j]) >> shift;
         (void)count_rank(s_cnt, b, valid);
     }
     __syncthreads();
@@ -399,6 +426,14 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
     __shared__ unsigned s_off[kBkMaxBuckets];      // slot of this block's first record in the bucket; bit 31: large bucket
     const GridParams<T>& g = *gp;
     const int NB = (g.ncells + (1 << shift) - 1) >> shift;
+    const int base = blockIdx.x * kBkBlockPts;
+    // the point loads do not depend on the prefix below: issued first, all together (clamped index instead of a branch)
+    T px[kBkPts], py[kBkPts], pz[kBkPts];
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const int i = min(base + j * kBkThreads + (int)threadIdx.x, n - 1);
+        px[j] = pts[3 * (size_t)i]; py[j] = pts[3 * (size_t)i + 1]; pz[j] = pts[3 * (size_t)i + 2];
+    }
     {   // exclusive prefix of the bucket totals (every block computes it: NB <= 4096 values)
         const int per = (NB + kBkThreads - 1) / kBkThreads;
         const int i0 = (int)threadIdx.x * per;
@@ -419,14 +454,12 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
         if (blockIdx.x == 0 && threadIdx.x == 0) bucket_start[NB] = total;
     }
     __syncthreads();
-    const int base = blockIdx.x * kBkBlockPts;
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
         const int i = base + j * kBkThreads + (int)threadIdx.x;
         const bool valid = i < n;
-        Pt4<T> p; p.x = p.y = p.z = (T)0; p.idx = i;
-        unsigned c = 0;
-        if (valid) { p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; c = cell_linear(g, p.x, p.y, p.z); }
+        Pt4<T> p; p.x = px[j]; p.y = py[j]; p.z = pz[j]; p.idx = i;
+        const unsigned c = cell_linear(g, p.x, p.y, p.z);
         const unsigned b = c >> shift;
         const unsigned r = count_rank(s_cnt, b, valid);
         unsigned so = 0;
@@ -460,16 +493,28 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     const bool large = e - s > kLargeBucket;
     for (int i = tid; i < CB; i += kSortThreads) s_cnt[i] = (large && i < ncl) ? cell_start[c0 + i] : 0u;
     __syncthreads();
-    unsigned rr[kSortIters];           // (cell in bucket) << 16 | rank in cell      (small buckets: <= 16384 records)
+    unsigned rr[kSortIters];           // (cell in bucket) << 16 | rank in cell      (small buckets: <= kLargeBucket records)
+    // Records are fetched kSortBatch trips at a time, all loads of a batch in flight together (clamped index instead of a
+    // branch around the load); the batch loop ends, wave-uniformly, with the bucket.
+    constexpr int kSortBatch = 4;
+    const unsigned last = e > s ? e - 1u : s;
     if (!large) {
 #pragma unroll
-        for (int it = 0; it < kSortIters; ++it) {
-            const unsigned p = s + (unsigned)(it * kSortThreads + tid);
-            rr[it] = 0;
-            if (p < e) {
-                const Pt4<T> rec = tmp[p];
-                const unsigned c = cell_linear(g, rec.x, rec.y, rec.z) - c0;
-                rr[it] = (c << 16) | atomicAdd(&s_cnt[c], 1u);
+        for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
+            Pt4<T> rec[kSortBatch];
+            const bool batch_on = s + (unsigned)(it0 * kSortThreads) < e;       // uniform in the block
+            if (batch_on) {
+#pragma unroll
+                for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
+            }
+#pragma unroll
+            for (int u = 0; u < kSortBatch; ++u) {
+                const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
+                rr[it0 + u] = 0;
+                if (batch_on && p < e) {
+                    const unsigned c = cell_linear(g, rec[u].x, rec[u].y, rec[u].z) - c0;
+                    rr[it0 + u] = (c << 16) | atomicAdd(&s_cnt[c], 1u);
+                }
             }
         }
         __syncthreads();
@@ -511,13 +556,19 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     if (large) return;
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < kSortIters; ++it) {
-        const unsigned p = s + (unsigned)(it * kSortThreads + tid);
-        if (p < e) {
-            const Pt4<T> rec = tmp[p];
-            const unsigned pos = s + s_cnt[rr[it] >> 16] + (rr[it] & 0xffffu);
-            sorted[pos] = rec;
-            if (pos_of) pos_of[rec.idx] = pos;
+    for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
+        if (!(s + (unsigned)(it0 * kSortThreads) < e)) break;                  // uniform in the block
+        Pt4<T> rec[kSortBatch];
+#pragma unroll
+        for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
+#pragma unroll
+        for (int u = 0; u < kSortBatch; ++u) {
+            const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
+            if (p < e) {
+                const unsigned pos = s + s_cnt[rr[it0 + u] >> 16] + (rr[it0 + u] & 0xffffu);
+                sorted[pos] = rec[u];
+                if (pos_of) pos_of[rec[u].idx] = pos;
+            }
         }
     }
 }

@@ -217,13 +217,13 @@ static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipSt
 // Enqueue the whole build on `s`: 4-5 launches, no memset, no host synchronisation. defer_large: the caller issues
 // index_large_pass itself (shared with the next build).
 template <typename T>
-static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false) {
+static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
     const int n = g.n;
     const int nb = (n + kBlock - 1) / kBlock;
     // bbox partials + zero-fill of the counters; the last block to finish also makes the grid (ticket: one of the context's
     // zeroed, self-resetting counters -- a different one for each build in flight)
     hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.n_zero,
-                       g.ticket, g.gp, occ, g.max_cells, g.sorted + n);
+                       g.ticket, g.gp, occ, g.max_cells, g.sorted + n, (unsigned*)zero2, n_zero2);   // zero2: the call's result block, zeroed on the way
     if (g.bucketed) {
         const int nblk = (n + kBkBlockPts - 1) / kBkBlockPts;
         hipLaunchKernelGGL(k_bucket_count<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max);
@@ -761,12 +761,12 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if ((rc = index_build(job.ridx, dr, occ, s, true))) break;
+        if ((rc = index_build(job.ridx, dr, occ, s, true, rb, (int)(sizeof(ResultBlock) / 4)))) break;
         if ((rc = index_build(job.qidx, dq, occ_q, s, true))) break;
         index_large_pass<T>(job.ridx, &job.qidx, s);
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
-        if ((rc = search_enqueue(c, s, job, st))) break;
+        if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
         if ((rc = unpermute_enqueue(s, job, dd, di))) break;          // optimistic: redone below if stragglers / ties remain
         tm.mark(2);
         HIP_TRY(hipMemcpyAsync(c->h_pinned, rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
@@ -827,13 +827,13 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (aalloc(ar, &P.xy.out_i, (size_t)nx) || aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
-    HIP_TRY(hipMemsetAsync(P.rb, 0, sizeof(ResultBlock), s));       // both directions' counters (+ the epilogue's ticket) in one fill
     tm.mark(0);
     // fork: cloud y is indexed on the aux stream while cloud x is indexed on s
     // (measured: the passes are throughput-bound, so the overlap only buys ~3 %; off unless PCU_HIP_TWO_STREAMS is set)
     hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
-    if (index_build(ix, P.dx, occ, s, s2 == s) || index_build(iy, P.dy, occ, s2, s2 == s)) return -1;
+    // (the first build's first kernel also zeroes the call's result block: both directions' counters + the epilogue's ticket)
+    if (index_build(ix, P.dx, occ, s, s2 == s, P.rb, (int)(sizeof(ResultBlock) / 4)) || index_build(iy, P.dy, occ, s2, s2 == s)) return -1;
     if (s2 == s) index_large_pass<T>(ix, &iy, s);
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));

@@ -3,18 +3,15 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/ab_pytest.txt
-for v in default w8 early flat93; do
+for v in default two_streams; do
   case $v in
     default) E="" ;;
-    w8) E="PCU_HIP_K1_W8=1" ;;
-    early) E="PCU_HIP_K1=early" ;;
-    flat93) E="PCU_HIP_K1=flat93" ;;
+    two_streams) E="PCU_HIP_TWO_STREAMS=1" ;;
   esac
   echo "== $v" >> gpurun_out/ab_bench.txt
   env $E timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline >> gpurun_out/ab_bench.txt 2>&1
 done
 timeout 600 python scratch/skew.py > gpurun_out/ab_skew.txt 2>&1
-echo '== occ sweep' >> gpurun_out/ab_skew.txt; timeout 300 python scratch/sweep_occ_chamfer.py 1000000 1.0 1.5 2.0 2.5 3.0 >> gpurun_out/ab_skew.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/ab_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/ab_trace.log 2>&1
 cd $GRAFT_REPO_ROOT
