@@ -29,7 +29,7 @@ from ._lib import Stats, set_cell_occupancy, device_count  # noqa: F401
 __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_distance", "chamfer_distance",
            "last_stats", "set_timing", "set_cell_occupancy", "device_count"]
 
-_last_stats = {}
+_last_stats = [None]      # the Stats struct of the most recent call (turned into a dict on demand)
 # PCU_HIP_NO_TIE_ORDER=1: skip the kd-tree tie-order resolver (exact ties then ordered by (d2, row)); for experiments.
 _ENV_FLAGS = _lib.NO_TIE_ORDER if __import__("os").environ.get("PCU_HIP_NO_TIE_ORDER", "0") not in ("", "0") else 0
 _TIMING = [int(__import__("os").environ.get("PCU_HIP_TIMING", "0") or 0)]
@@ -50,7 +50,8 @@ def _flags():
 
 def last_stats():
     """Statistics of the most recent call (escalations, tie handling, device milliseconds)."""
-    return dict(_last_stats)
+    st = _last_stats[0]
+    return st.as_dict() if st is not None else {}
 
 
 def _is_torch(a):
@@ -66,9 +67,22 @@ def _shape2(a):
     raise ValueError(f"Invalid number of dimensions ({len(sh)}): expected a matrix of shape (n, 3).")
 
 
+_DT_FAST = {np.dtype("float32"): "float32", np.dtype("float64"): "float64"}
+
+
 def _dtype_name(a):
+    dt = getattr(a, "dtype", None)
+    try:
+        name = _DT_FAST.get(dt)            # the two supported dtypes, numpy or torch, without string work
+    except TypeError:
+        name = None
+    if name is not None:
+        return name
     if _is_torch(a):
-        return str(a.dtype).replace("torch.", "")
+        name = str(a.dtype).replace("torch.", "")
+        if name in ("float32", "float64"):
+            _DT_FAST[a.dtype] = name
+        return name
     return np.asarray(a).dtype.name
 
 
@@ -142,8 +156,18 @@ class _Dev:
 
 
 def _record(st):
-    _last_stats.clear()
-    _last_stats.update(st.as_dict())
+    _last_stats[0] = st
+
+
+_FN = {}
+
+
+def _fn(op, suffix):
+    """Entry point `pcu_hip_<op>_<suffix>` (looked up once)."""
+    f = _FN.get((op, suffix))
+    if f is None:
+        f = _FN[(op, suffix)] = getattr(_lib.lib(), f"pcu_hip_{op}_{suffix}")
+    return f
 
 
 def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False, max_points_per_leaf=10,
@@ -174,9 +198,8 @@ def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False
     corrs = d.empty((n, k), "i64")
     st = Stats()
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
-    with _lib.lock():
-        rc = getattr(_lib.lib(), "pcu_hip_knn_" + d.suffix)(d.ctx, d.pa, n, d.pb, m, k, int(max_points_per_leaf), _Dev.ptr(dists), _Dev.ptr(corrs),
-                                                           flags, d.stream, ctypes.addressof(st))
+    rc = _fn("knn", d.suffix)(d.ctx, d.pa, n, d.pb, m, k, int(max_points_per_leaf), _Dev.ptr(dists), _Dev.ptr(corrs),
+                              flags, d.stream, ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
     # npe::move(..., squeeze): a matrix with a singleton dimension comes back 1-D
@@ -213,10 +236,9 @@ def one_sided_hausdorff_distance(source, target, return_index=True, squared_dist
     oj = np.zeros(2, dtype=np.int64)
     st = Stats()
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
-    with _lib.lock():
-        rc = getattr(_lib.lib(), "pcu_hip_one_sided_hausdorff_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
-            ctypes.addressof(st))
+    rc = _fn("one_sided_hausdorff", d.suffix)(
+        d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
+        ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
     if return_index:
@@ -247,10 +269,9 @@ def hausdorff_distance(x, y, return_index=False, squared_distances=False, max_po
     oj = np.zeros(2, dtype=np.int64)
     st = Stats()
     flags = d.flags | (_lib.SQUARED if squared_distances else 0)
-    with _lib.lock():   # one call: both clouds are indexed once and searched in both directions
-        rc = getattr(_lib.lib(), "pcu_hip_hausdorff_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
-            ctypes.addressof(st))
+    rc = _fn("hausdorff", d.suffix)(   # one call: both clouds are indexed once and searched in both directions
+        d.ctx, d.pa, n, d.pb, m, int(max_points_per_leaf), od.ctypes.data, oi.ctypes.data, oj.ctypes.data, flags, d.stream,
+        ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
     # point_cloud_utils/__init__.py:69-81, on Python floats exactly as there
@@ -287,18 +308,19 @@ def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10)
     n, m = int(d.a.shape[0]), int(d.b.shape[0])
     cxy = d.empty((n,), "i64") if return_index else None
     cyx = d.empty((m,), "i64") if return_index else None
-    means = np.zeros(2, dtype=np.float64)
+    means = (ctypes.c_double * 2)()
     st = Stats()
-    with _lib.lock():
-        rc = getattr(_lib.lib(), "pcu_hip_chamfer_" + d.suffix)(
-            d.ctx, d.pa, n, d.pb, m, float(p_norm), int(max_points_per_leaf), means.ctypes.data, _Dev.ptr(cxy), _Dev.ptr(cyx),
-            d.flags, d.stream, ctypes.addressof(st))
-    _lib.check(rc)
+    rc = _fn("chamfer", d.suffix)(
+        d.ctx, d.pa, n, d.pb, m, float(p_norm), int(max_points_per_leaf), ctypes.addressof(means), _Dev.ptr(cxy), _Dev.ptr(cyx),
+        d.flags, d.stream, ctypes.addressof(st))
+    if rc:
+        _lib.check(rc)
     _record(st)
-    # __init__.py:112-115: both means are scalars of the input dtype; their sum is the result
+    # __init__.py:112-115: both means are scalars of the input dtype (np.mean of such a scalar is that scalar);
+    # their sum, in that dtype, is the result
     dists_x_to_y = d.np_dtype(means[1])      # norm(x[corrs_y_to_x] - y).mean()
     dists_y_to_x = d.np_dtype(means[0])      # norm(y[corrs_x_to_y] - x).mean()
-    cham_dist = np.mean(dists_x_to_y) + np.mean(dists_y_to_x)
+    cham_dist = dists_x_to_y + dists_y_to_x
     if return_index:
         return cham_dist, cxy, cyx
     return cham_dist

@@ -477,7 +477,11 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
                                                               const Pt4<T>* __restrict__ tmp, unsigned* cell_start, Pt4<T>* __restrict__ sorted,
-                                                              unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large) {
+                                                              unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large,
+                                                              long long* prof = nullptr) {
+    // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
+    long long t_prev = prof ? wall_clock64() : 0;
+#define BK_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
     __shared__ unsigned s_cnt[kBkMaxCellsPerBucket];
     __shared__ unsigned s_w[kSortThreads / 64 + 1];
     __shared__ unsigned long long s_q[kSortThreads / 64];
@@ -491,8 +495,10 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     const int ncl = min(CB, g.ncells - (int)c0);
     const unsigned s = bucket_start[b], e = bucket_start[b + 1];
     const bool large = e - s > kLargeBucket;
+    BK_PROF(0);
     for (int i = tid; i < CB; i += kSortThreads) s_cnt[i] = (large && i < ncl) ? cell_start[c0 + i] : 0u;
     __syncthreads();
+    BK_PROF(1);
     unsigned rr[kSortIters];           // (cell in bucket) << 16 | rank in cell      (small buckets: <= kLargeBucket records)
     // Records are fetched kSortBatch trips at a time, all loads of a batch in flight together (clamped index instead of a
     // branch around the load); the batch loop ends, wave-uniformly, with the bucket.
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
 #pragma unroll
                 for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
             }
+
 #pragma unroll
             for (int u = 0; u < kSortBatch; ++u) {
                 const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
         }
         __syncthreads();
     }
+    BK_PROF(2);
     // exclusive scan of the CB counters (thread-contiguous items), cell_start, balance metric
     const int per = CB >= kSortThreads ? CB / kSortThreads : 1;
     const int i0 = tid * per;
@@ -555,12 +563,13 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     }
     if (large) return;
     __syncthreads();
+    BK_PROF(3);
 #pragma unroll
     for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
         if (!(s + (unsigned)(it0 * kSortThreads) < e)) break;                  // uniform in the block
         Pt4<T> rec[kSortBatch];
 #pragma unroll
-        for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
+        for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];      // (re-read: L2 hit; keeping them in registers measured slower)
 #pragma unroll
         for (int u = 0; u < kSortBatch; ++u) {
             const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
@@ -571,6 +580,8 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
             }
         }
     }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BK_PROF(4); if (threadIdx.x == 0) atomicAdd((unsigned long long*)&prof[7], 1ull); }
+#undef BK_PROF
 }
 
 template <typename T>

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <atomic>
 
 #include "../../include/pcu_hip.h"
 #include "grid.h"
@@ -48,6 +50,7 @@ struct pcu_hip_ctx {
     int n_kev = 0;
     double occupancy = 0;                      // <=0: default
     int* h_pinned = nullptr;                   // small pinned readback buffer
+    unsigned seq = 0;                                        // sequence number of the result block the epilogue kernel writes to h_pinned
     bool time_phases = false, time_kernels = false;          // HIP-event timing of this call (flags PCU_HIP_TIME_*): each event is a
                                                              // ~6 us bubble in the kernel pipeline, so both are opt-in
     unsigned* tickets = nullptr; unsigned ticket_next = 0;   // 64 zeroed, self-resetting last-block counters (index builds)
@@ -222,15 +225,29 @@ static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t 
     const int nb = (n + kBlock - 1) / kBlock;
     // bbox partials + zero-fill of the counters; the last block to finish also makes the grid (ticket: one of the context's
     // zeroed, self-resetting counters -- a different one for each build in flight)
+    // PCU_HIP_FUSED_GRID=1: the last bbox block also makes the grid (one launch less). Measured on MI355X the fused kernel
+    // takes 11 / 14 / 19 us depending on which block arrives last, the two launches 6 + 4.7 us every time: off by default.
+    static const bool fused = getenv("PCU_HIP_FUSED_GRID") != nullptr;
     hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.n_zero,
-                       g.ticket, g.gp, occ, g.max_cells, g.sorted + n, (unsigned*)zero2, n_zero2);   // zero2: the call's result block, zeroed on the way
+                       fused ? g.ticket : nullptr, g.gp, occ, g.max_cells, g.sorted + n, (unsigned*)zero2, n_zero2);   // zero2: the call's result block, zeroed on the way
+    if (!fused) hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells, g.sorted + n);
     if (g.bucketed) {
         const int nblk = (n + kBkBlockPts - 1) / kBkBlockPts;
         hipLaunchKernelGGL(k_bucket_count<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max);
         hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max,
                            g.bucket_start, g.tmp, g.cell_start, g.rank);
+        static long long* prof = nullptr;       // PCU_HIP_PROF_BUILD: stage times of k_bucket_sort, printed per build (synchronises)
+        static const bool do_prof = getenv("PCU_HIP_PROF_BUILD") != nullptr;
+        if (do_prof && !prof) HIP_TRY(hipMalloc((void**)&prof, 8 * sizeof(long long)));
+        if (do_prof) HIP_TRY(hipMemsetAsync(prof, 0, 8 * sizeof(long long), s));
         hipLaunchKernelGGL(k_bucket_sort<T>, dim3(g.nb_max), dim3(kSortThreads), 0, s, g.gp, g.shift, g.bucket_start, g.tmp, g.cell_start, g.sorted,
-                           g.pos_of, g.large_list, g.n_large);
+                           g.pos_of, g.large_list, g.n_large, do_prof ? prof : nullptr);
+        if (do_prof) {
+            long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            const double nb = h[7] > 0 ? (double)h[7] : 1.0;
+            fprintf(stderr, "[bucket_sort prof] blocks %lld | mean us per block: head %.2f  zero+sync %.2f  load+rank %.2f  scan %.2f  place %.2f\n", h[7],
+                    h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0, h[4] / nb / 100.0);
+        }
         if (!defer_large) index_large_pass<T>(g, nullptr, s);
     } else {
         hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
@@ -847,11 +864,29 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     tm.mark(2);
     return 0;
 }
+// The epilogue kernel's last block writes the result block into pinned host memory and then the call's sequence number
+// into its last word: the host spins on that word (a few hundred ns after the store) instead of paying a stream
+// synchronisation's wake-up latency (tens of us per call). Everything enqueued before that kernel has completed by then
+// (in-order stream). With event timing on, or if the word does not arrive, fall back to hipStreamSynchronize.
+static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
+    static const bool no_spin = getenv("PCU_HIP_NO_SPIN") != nullptr;
+    if (!no_spin && !c->time_phases && !c->time_kernels) {
+        volatile int* flag = c->h_pinned + 63;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            if ((unsigned)*flag == c->seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+            if ((it & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // long call or fault: block instead
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) return fail(PCU_HIP_ERR_RUNTIME, "internal: the epilogue kernel did not deliver its result block");
+    return 0;
+}
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
 template <typename T>
 static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false) {
-    if (!copied_by_kernel) HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
+    else if (wait_result_block(c, s)) return -1;
     memcpy(host, c->h_pinned, sizeof(ResultBlock));
     int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
     if (r1 < 0) return r1;
@@ -871,7 +906,7 @@ static int argmax_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, bool t
     ArgmaxSide<T> b = a; b.n = 0; b.nb = 0;
     if (two_sided) b = side(P.yx);
     hipLaunchKernelGGL(k_argmax_pair<T>, dim3(a.nb + b.nb), dim3(kBlock), 0, s, a, b, P.pv, P.pi, P.res_v, P.res_ij,
-                       reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned);
+                       reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -978,7 +1013,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
             // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
             const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx}, sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby};
             hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
-                               reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned);
+                               reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
             HIP_TRY(hipGetLastError());
             tm.mark(3);
             if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }

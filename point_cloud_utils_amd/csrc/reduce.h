@@ -83,7 +83,7 @@ __device__ __forceinline__ void block_argmax(T& v, long long& idx) {
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, const ArgmaxSide<T> s1, T* pv, long long* pi,
-                                                        T* out_v, long long* out_ij, unsigned* ticket, const int* result_block, int* host_block) {
+                                                        T* out_v, long long* out_ij, unsigned* ticket, const int* result_block, int* host_block, unsigned seq) {
     const bool second = (int)blockIdx.x >= s0.nb;
     const ArgmaxSide<T>& sd = second ? s1 : s0;
     const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
@@ -112,9 +112,10 @@ __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, 
     }
     if (threadIdx.x == 0) { *ticket = 0u; wait_stores(); }
     __syncthreads();
-    if (host_block && threadIdx.x < 64) {
-        host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
+    if (host_block && threadIdx.x < 64) {       // one wave: 63 data words, system-scope fence, then the sequence word the host spins on
+        if (threadIdx.x < 63) host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
         __threadfence_system();
+        if (threadIdx.x == 63) { __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 
@@ -171,7 +172,7 @@ struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; c
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, const PnormSide<T> s1, int pcode, double p, double* partial,
-                                                       double* out_sums, unsigned* ticket, const int* result_block, int* host_block) {
+                                                       double* out_sums, unsigned* ticket, const int* result_block, int* host_block, unsigned seq) {
     const bool second = (int)blockIdx.x >= s0.nb;
     const PnormSide<T>& sd = second ? s1 : s0;
     const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
     const double r1 = block_sum(a1);
     if (threadIdx.x == 0) { out_sums[0] = r0; out_sums[1] = r1; *ticket = 0u; wait_stores(); }
     __syncthreads();
-    if (host_block && threadIdx.x < 64) {
-        host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
+    if (host_block && threadIdx.x < 64) {       // one wave: 63 data words, system-scope fence, then the sequence word the host spins on
+        if (threadIdx.x < 63) host_block[threadIdx.x] = peek(&result_block[threadIdx.x]);
         __threadfence_system();
+        if (threadIdx.x == 63) { __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 

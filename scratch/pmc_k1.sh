@@ -23,7 +23,7 @@ for d in sorted(glob.glob('gpurun_out/pmc/*/')):
         k = row['Kernel_Name'][:40]
         acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
     for k in acc:
-        if 'k_search1' in k or 'k_bucket_sort' in k:
+        if 'k_search1_flat' in k or 'k_bucket_count' in k:
             print(k, {c: round(sum(v)/len(v)) for c, v in acc[k].items()}, 'n=', len(next(iter(acc[k].values()))))
 PY
 grep -c . gpurun_out/pmc/avail.txt
