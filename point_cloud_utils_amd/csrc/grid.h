@@ -57,23 +57,15 @@ constexpr int kBboxBlocks = 256;   // one per CU; partial[b][0..2] = min xyz, [3
 // writes one partial; k_make_grid folds the kBboxBlocks partials. The same launch zero-fills the cell
 // counters (so the build needs no separate memset launch).
 template <typename T>
-__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel);
-
-// With `ticket` (a zeroed, self-resetting counter) the block that finishes last also folds the partials and makes the
-// grid (make_grid_body), which saves the separate single-block k_make_grid launch (~4.5 us of launch floor per build).
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ pts, int n, T* partial,
-                                                         unsigned* __restrict__ counts, int n_counts,
-                                                         unsigned* ticket = nullptr, GridParams<T>* gp = nullptr, double occupancy = 0,
-                                                         int max_cells = 0, Pt4<T>* sentinel = nullptr,
-                                                         unsigned* __restrict__ zero2 = nullptr, int n_zero2 = 0) {
+__device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* partial, unsigned* __restrict__ counts, int n_counts,
+                                          unsigned* __restrict__ zero2, int n_zero2, const int bid, const int nblk) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     // four points = 12 consecutive scalars = three 16-byte (f32) loads per trip, all in flight together; a plain
     // point-per-trip loop waits for memory 15 times per thread at n = 1M
     struct __attribute__((packed, aligned(4))) Vec4 { T v[4]; };
     const int n4 = n >> 2;
-    const int gtid = blockIdx.x * kBlock + threadIdx.x, gstride = gridDim.x * kBlock;
+    const int gtid = bid * kBlock + (int)threadIdx.x, gstride = nblk * kBlock;
     for (int gi = gtid; gi < n4; gi += gstride) {
         const Vec4* p = reinterpret_cast<const Vec4*>(pts + 12 * (size_t)gi);
         const Vec4 a = p[0], b = p[1], c = p[2];
@@ -112,18 +104,22 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const T* __restrict__ p
         const int j = threadIdx.x;
         T a = s_lo[0][j], b = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
-        publish(&partial[blockIdx.x * 6 + j], a);
-        publish(&partial[blockIdx.x * 6 + 3 + j], b);
-        wait_stores();
+        partial[bid * 6 + j] = a;
+        partial[bid * 6 + 3 + j] = b;
     }
-    if (!ticket) return;
-    __shared__ bool s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = take_ticket(ticket, gridDim.x);
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) *ticket = 0u;
-    make_grid_body<T>(gp, partial, (int)gridDim.x, n, occupancy, max_cells, sentinel);
+}
+
+// Both clouds of a call are indexed by the SAME launches: blocks [0, nb0) work on side 0, the rest on side 1 (a side with
+// n = 0 gets no blocks). The build passes are latency-bound (1-3 TB/s), so two clouds per launch cost far less than two
+// launches, and the launch count of a two-sided call halves.
+template <typename T>
+struct BboxSide { const T* pts; int n; T* partial; unsigned* counts; int n_counts; unsigned* zero2; int n_zero2; };
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bbox_partial(const BboxSide<T> a0, const BboxSide<T> a1, int nb0) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BboxSide<T>& a = second ? a1 : a0;
+    bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, second ? (int)blockIdx.x - nb0 : (int)blockIdx.x,
+                 second ? (int)gridDim.x - nb0 : nb0);
 }
 
 // One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
@@ -137,7 +133,7 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
         for (int b = threadIdx.x; b < nparts; b += kBlock)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T a = peek(&partial[b * 6 + j]), c = peek(&partial[b * 6 + 3 + j]);
+                T a = partial[b * 6 + j], c = partial[b * 6 + 3 + j];
                 lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
             }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -194,9 +190,11 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
     gp->sumsq = 0ull; gp->closed = 0;
 }
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_make_grid(GridParams<T>* gp, const T* partial, int nparts,
-                                                      int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
-    make_grid_body<T>(gp, partial, nparts, n, occupancy, max_cells, sentinel);
+struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; };
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_make_grid(const GridSide<T> a0, const GridSide<T> a1) {      // one block per side
+    const GridSide<T>& a = blockIdx.x ? a1 : a0;
+    make_grid_body<T>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel);
 }
 
 template <typename T>
@@ -361,8 +359,13 @@ constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
 constexpr int kBkMaxBuckets = 4096;
 constexpr int kBkMaxCellsPerBucket = 4096;
 constexpr int kSortThreads = PCU_SORT_THREADS;
-constexpr int kSortIters = 16;
-constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 16384 points
+constexpr int kSortIters = 8;                       // (16 costs 8 more VGPRs: 3 instead of 4 resident blocks per CU)
+constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 4096 points = twice the mean bucket
+constexpr int kStageRecs = 2240;                    // records of a bucket staged in LDS for the coalesced copy-out (mean bucket 2048, sigma 45)
+
+template <typename T> struct RawRec;
+template <> struct RawRec<float>  { typedef unsigned __attribute__((ext_vector_type(4))) type; };
+template <> struct RawRec<double> { typedef unsigned long long __attribute__((ext_vector_type(4))) type; };
 
 template <typename T>
 __device__ __forceinline__ unsigned cell_linear(const GridParams<T>& g, T x, T y, T z) {
@@ -390,14 +393,14 @@ __device__ __forceinline__ unsigned count_rank(unsigned* counter, unsigned key, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_count(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
+__device__ __forceinline__ void bucket_count_body(const int bid, const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
                                                              unsigned* bucket_total, unsigned* __restrict__ block_base, int nb_stride) {
     __shared__ unsigned s_cnt[kBkMaxBuckets];
     const GridParams<T>& g = *gp;
     const int NB = (g.ncells + (1 << shift) - 1) >> shift;
     for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
     __syncthreads();
-    const int base = blockIdx.x * kBkBlockPts;
+    const int base = bid * kBkBlockPts;
     T px[kBkPts], py[kBkPts], pz[kBkPts];            // all loads first (clamped index, no branch): one wait instead of kBkPts
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
@@ -413,12 +416,26 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const T* __restrict
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += kBkThreads) {
         const unsigned c = s_cnt[i];
-        block_base[(size_t)blockIdx.x * nb_stride + i] = c ? atomicAdd(&bucket_total[i], c) : 0u;
+        block_base[(size_t)bid * nb_stride + i] = c ? atomicAdd(&bucket_total[i], c) : 0u;
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
+struct BucketSide {        // one cloud's view of the bucket passes
+    const T* pts; int n; GridParams<T>* gp; int shift; int nb_stride;
+    unsigned *bucket_total, *block_base, *bucket_start; Pt4<T>* tmp; unsigned *cell_start, *rank_tmp;
+    Pt4<T>* sorted; unsigned *pos_of, *large_list, *n_large;
+};
+template <typename T>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_count(const BucketSide<T> a0, const BucketSide<T> a1, int nb0) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BucketSide<T>& a = second ? a1 : a0;
+    bucket_count_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.block_base, a.nb_stride);
+}
+
+
+template <typename T>
+__device__ __forceinline__ void bucket_scatter_body(const int bid, const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
                                                                const unsigned* __restrict__ bucket_total, const unsigned* __restrict__ block_base,
                                                                int nb_stride, unsigned* __restrict__ bucket_start, Pt4<T>* __restrict__ tmp,
                                                                unsigned* cell_counts, unsigned* __restrict__ rank_tmp) {
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
     __shared__ unsigned s_off[kBkMaxBuckets];      // slot of this block's first record in the bucket; bit 31: large bucket
     const GridParams<T>& g = *gp;
     const int NB = (g.ncells + (1 << shift) - 1) >> shift;
-    const int base = blockIdx.x * kBkBlockPts;
+    const int base = bid * kBkBlockPts;
     // the point loads do not depend on the prefix below: issued first, all together (clamped index instead of a branch)
     T px[kBkPts], py[kBkPts], pz[kBkPts];
 #pragma unroll
@@ -445,13 +462,13 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
             const int i = i0 + q;
             if (i < NB) {
                 const unsigned t = bucket_total[i];
-                s_off[i] = (ex + block_base[(size_t)blockIdx.x * nb_stride + i]) | (t > kLargeBucket ? 0x80000000u : 0u);
+                s_off[i] = (ex + block_base[(size_t)bid * nb_stride + i]) | (t > kLargeBucket ? 0x80000000u : 0u);
                 s_cnt[i] = 0;
-                if (blockIdx.x == 0) bucket_start[i] = ex;
+                if (bid == 0) bucket_start[i] = ex;
                 ex += t;
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) bucket_start[NB] = total;
+        if (bid == 0 && threadIdx.x == 0) bucket_start[NB] = total;
     }
     __syncthreads();
 #pragma unroll
@@ -475,20 +492,32 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const T* __restri
 }
 
 template <typename T>
-__global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
+__global__ __launch_bounds__(kBkThreads) void k_bucket_scatter(const BucketSide<T> a0, const BucketSide<T> a1, int nb0) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BucketSide<T>& a = second ? a1 : a0;
+    bucket_scatter_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.block_base, a.nb_stride,
+                           a.bucket_start, a.tmp, a.cell_start, a.rank_tmp);
+}
+
+
+template <typename T>
+__device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
                                                               const Pt4<T>* __restrict__ tmp, unsigned* cell_start, Pt4<T>* __restrict__ sorted,
                                                               unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large,
-                                                              long long* prof = nullptr) {
+                                                              long long* prof, const int cnt_cap) {
     // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
     long long t_prev = prof ? wall_clock64() : 0;
 #define BK_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
-    __shared__ unsigned s_cnt[kBkMaxCellsPerBucket];
+    // dynamic LDS: [cnt_cap counters][kStageRecs records] (cnt_cap = the largest 2^shift of the launch's sides)
+    extern __shared__ __attribute__((aligned(32))) unsigned char s_dyn[];
+    unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_dyn);
+    Pt4<T>* const s_stage = reinterpret_cast<Pt4<T>*>(s_dyn + (size_t)cnt_cap * 4);
     __shared__ unsigned s_w[kSortThreads / 64 + 1];
     __shared__ unsigned long long s_q[kSortThreads / 64];
     const GridParams<T>& g = *gp;
     const int CB = 1 << shift;
     const int NB = (g.ncells + CB - 1) >> shift;
-    const int b = blockIdx.x;
+    const int b = bid;
     if (b >= NB) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned c0 = (unsigned)b << shift;
@@ -504,6 +533,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     // branch around the load); the batch loop ends, wave-uniformly, with the bucket.
     constexpr int kSortBatch = 4;
     const unsigned last = e > s ? e - 1u : s;
+    const bool staged = e - s <= (unsigned)kStageRecs;      // the bucket fits the LDS stage (the normal case)
     if (!large) {
 #pragma unroll
         for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
@@ -513,7 +543,6 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
 #pragma unroll
                 for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
             }
-
 #pragma unroll
             for (int u = 0; u < kSortBatch; ++u) {
                 const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
@@ -521,6 +550,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
                 if (batch_on && p < e) {
                     const unsigned c = cell_linear(g, rec[u].x, rec[u].y, rec[u].z) - c0;
                     rr[it0 + u] = (c << 16) | atomicAdd(&s_cnt[c], 1u);
+                    if (staged) s_stage[p - s] = rec[u];          // parked in arrival order; permuted in place below
                 }
             }
         }
@@ -564,25 +594,65 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(GridParams<T>* gp,
     if (large) return;
     __syncthreads();
     BK_PROF(3);
+    // Placement. A bucket that fits the LDS stage is permuted there, in place (every thread takes its records out, barrier,
+    // puts them into their sorted slots), and leaves as one contiguous, fully coalesced copy: no second pass over `tmp`
+    // and whole 128-byte lines instead of one scattered 16-byte store per record. Larger buckets re-read and store directly.
+    if (staged) {
+        constexpr int kStageIters = (kStageRecs + kSortThreads - 1) / kSortThreads;       // 5 trips cover the stage
+        static_assert(kStageIters == 5, "unrolled by hand");
+        typedef typename RawRec<T>::type Raw;                 // a record as one vector register tuple (a struct copy goes through scratch)
+        Raw* const raw = reinterpret_cast<Raw*>(s_stage);
+        const unsigned cnt = e - s;
+        const unsigned lastl = cnt ? cnt - 1u : 0u;
+        const Raw m0 = raw[min((unsigned)tid, lastl)];
+        const Raw m1 = raw[min((unsigned)(tid + kSortThreads), lastl)];
+        const Raw m2 = raw[min((unsigned)(tid + 2 * kSortThreads), lastl)];
+        const Raw m3 = raw[min((unsigned)(tid + 3 * kSortThreads), lastl)];
+        const Raw m4 = raw[min((unsigned)(tid + 4 * kSortThreads), lastl)];
+        __syncthreads();
+        if ((unsigned)tid < cnt) raw[s_cnt[rr[0] >> 16] + (rr[0] & 0xffffu)] = m0;
+        if ((unsigned)(tid + kSortThreads) < cnt) raw[s_cnt[rr[1] >> 16] + (rr[1] & 0xffffu)] = m1;
+        if ((unsigned)(tid + 2 * kSortThreads) < cnt) raw[s_cnt[rr[2] >> 16] + (rr[2] & 0xffffu)] = m2;
+        if ((unsigned)(tid + 3 * kSortThreads) < cnt) raw[s_cnt[rr[3] >> 16] + (rr[3] & 0xffffu)] = m3;
+        if ((unsigned)(tid + 4 * kSortThreads) < cnt) raw[s_cnt[rr[4] >> 16] + (rr[4] & 0xffffu)] = m4;
+        __syncthreads();
+        for (unsigned i = tid; i < e - s; i += kSortThreads) {
+            const Pt4<T> r = s_stage[i];
+            sorted[s + i] = r;
+            if (pos_of) pos_of[r.idx] = s + i;
+        }
+    } else {
 #pragma unroll
-    for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
-        if (!(s + (unsigned)(it0 * kSortThreads) < e)) break;                  // uniform in the block
-        Pt4<T> rec[kSortBatch];
+        for (int it0 = 0; it0 < kSortIters; it0 += kSortBatch) {
+            if (!(s + (unsigned)(it0 * kSortThreads) < e)) break;                  // uniform in the block
+            Pt4<T> rec[kSortBatch];
 #pragma unroll
-        for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];      // (re-read: L2 hit; keeping them in registers measured slower)
+            for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
 #pragma unroll
-        for (int u = 0; u < kSortBatch; ++u) {
-            const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
-            if (p < e) {
-                const unsigned pos = s + s_cnt[rr[it0 + u] >> 16] + (rr[it0 + u] & 0xffffu);
-                sorted[pos] = rec[u];
-                if (pos_of) pos_of[rec[u].idx] = pos;
+            for (int u = 0; u < kSortBatch; ++u) {
+                const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
+                if (p < e) {
+                    const unsigned pos = s + s_cnt[rr[it0 + u] >> 16] + (rr[it0 + u] & 0xffffu);
+                    sorted[pos] = rec[u];
+                    if (pos_of) pos_of[rec[u].idx] = pos;
+                }
             }
         }
     }
     if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BK_PROF(4); if (threadIdx.x == 0) atomicAdd((unsigned long long*)&prof[7], 1ull); }
 #undef BK_PROF
 }
+
+template <typename T>
+__global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const BucketSide<T> a0, const BucketSide<T> a1, int nb0, long long* prof, int cnt_cap) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BucketSide<T>& a = second ? a1 : a0;
+    bucket_sort_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.gp, a.shift, a.bucket_start, a.tmp, a.cell_start, a.sorted, a.pos_of,
+                        a.large_list, a.n_large, prof, cnt_cap);
+}
+template <typename T>
+static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + (size_t)kStageRecs * sizeof(Pt4<T>); }
+
 
 template <typename T>
 struct LargeJob {

@@ -53,7 +53,6 @@ struct pcu_hip_ctx {
     unsigned seq = 0;                                        // sequence number of the result block the epilogue kernel writes to h_pinned
     bool time_phases = false, time_kernels = false;          // HIP-event timing of this call (flags PCU_HIP_TIME_*): each event is a
                                                              // ~6 us bubble in the kernel pipeline, so both are opt-in
-    unsigned* tickets = nullptr; unsigned ticket_next = 0;   // 64 zeroed, self-resetting last-block counters (index builds)
     // tie-order resolver: its own grow-only workspace (stable addresses across calls, so the captured
     // level-pair graph below stays valid) and one cached executable graph per scalar type
     char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
@@ -144,7 +143,6 @@ struct GridIndex {
     T* bbox_partial = nullptr;
     int n = 0, max_cells = 0, scan_blocks = 0;
     unsigned* pos_of = nullptr;           // row -> slot in `sorted` (only when asked for: k_unpermute)
-    unsigned* ticket = nullptr;           // last-block ticket of the build's first launch
     // bucketed build (grid.h): cells per bucket = 1 << shift; nb_max = host bound on the number of buckets
     bool bucketed = false; int shift = 0, nb_max = 0, n_zero = 0;
     Pt4<T>* tmp = nullptr; unsigned *bucket_total = nullptr, *bucket_start = nullptr, *block_base = nullptr, *large_list = nullptr, *n_large = nullptr;
@@ -195,7 +193,6 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
     if (aalloc(a, &g.bbox_partial, (size_t)kBboxBlocks * 6)) return -1;
     g.n_zero = g.max_cells + 1;
-    g.ticket = a.c->tickets + (a.c->ticket_next++ & 63);
     if (g.bucketed) {
         g.bucket_total = g.cell_start + g.max_cells + 1; g.n_large = g.bucket_total + g.nb_max; g.n_zero = g.max_cells + 1 + g.nb_max + 1;
         if (aalloc(a, &g.tmp, (size_t)n)) return -1;
@@ -217,39 +214,68 @@ static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipSt
     const LargeJob<T> ja = large_job(ua ? a : *b), jb = large_job(ua && ub ? *b : (ua ? a : *b));
     hipLaunchKernelGGL(k_bucket_large<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, ja, jb, (ua && ub) ? 2 : 1);
 }
-// Enqueue the whole build on `s`: 4-5 launches, no memset, no host synchronisation. defer_large: the caller issues
-// index_large_pass itself (shared with the next build).
+// Enqueue the build of one or two indexes on `s`: every pass is ONE launch serving both clouds (grid.h: blocks [0, nb0)
+// work on the first, the rest on the second). No memset, no host synchronisation. zero2: a small region (the call's
+// result block) zeroed on the way by the first launch.
 template <typename T>
-static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
-    const int n = g.n;
-    const int nb = (n + kBlock - 1) / kBlock;
-    // bbox partials + zero-fill of the counters; the last block to finish also makes the grid (ticket: one of the context's
-    // zeroed, self-resetting counters -- a different one for each build in flight)
-    // PCU_HIP_FUSED_GRID=1: the last bbox block also makes the grid (one launch less). Measured on MI355X the fused kernel
-    // takes 11 / 14 / 19 us depending on which block arrives last, the two launches 6 + 4.7 us every time: off by default.
-    static const bool fused = getenv("PCU_HIP_FUSED_GRID") != nullptr;
-    hipLaunchKernelGGL(k_bbox_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, n, g.bbox_partial, g.cell_start, g.n_zero,
-                       fused ? g.ticket : nullptr, g.gp, occ, g.max_cells, g.sorted + n, (unsigned*)zero2, n_zero2);   // zero2: the call's result block, zeroed on the way
-    if (!fused) hipLaunchKernelGGL(k_make_grid<T>, dim3(1), dim3(kBlock), 0, s, g.gp, g.bbox_partial, kBboxBlocks, n, occ, g.max_cells, g.sorted + n);
-    if (g.bucketed) {
-        const int nblk = (n + kBkBlockPts - 1) / kBkBlockPts;
-        hipLaunchKernelGGL(k_bucket_count<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max);
-        hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(nblk), dim3(kBkThreads), 0, s, d_pts, n, g.gp, g.shift, g.bucket_total, g.block_base, g.nb_max,
-                           g.bucket_start, g.tmp, g.cell_start, g.rank);
+static BucketSide<T> bucket_side(const GridIndex<T>& g, const T* pts) {
+    return BucketSide<T>{pts, g.n, g.gp, g.shift, g.nb_max, g.bucket_total, g.block_base, g.bucket_start, g.tmp, g.cell_start, g.rank,
+                         g.sorted, g.pos_of, g.large_list, g.n_large};
+}
+template <typename T>
+static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex<T>* b, const T* pb, double occb, hipStream_t s,
+                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
+    {
+        const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2};
+        const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
+        hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
+        const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n};
+        const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n} : g0;
+        hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
+    }
+    // bucketed sides share their launches; a side too small / too coarse for buckets takes the atomic passes
+    const GridIndex<T>* bs[2]; const T* bp[2]; int nbs = 0;
+    if (a.bucketed) { bs[nbs] = &a; bp[nbs] = pa; ++nbs; }
+    if (b && b->bucketed) { bs[nbs] = b; bp[nbs] = pb; ++nbs; }
+    if (nbs) {
+        const BucketSide<T> s0 = bucket_side(*bs[0], bp[0]), s1 = nbs > 1 ? bucket_side(*bs[1], bp[1]) : s0;
+        const int c0 = (bs[0]->n + kBkBlockPts - 1) / kBkBlockPts, c1 = nbs > 1 ? (bs[1]->n + kBkBlockPts - 1) / kBkBlockPts : 0;
+        hipLaunchKernelGGL(k_bucket_count<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+        hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
         static long long* prof = nullptr;       // PCU_HIP_PROF_BUILD: stage times of k_bucket_sort, printed per build (synchronises)
         static const bool do_prof = getenv("PCU_HIP_PROF_BUILD") != nullptr;
         if (do_prof && !prof) HIP_TRY(hipMalloc((void**)&prof, 8 * sizeof(long long)));
         if (do_prof) HIP_TRY(hipMemsetAsync(prof, 0, 8 * sizeof(long long), s));
-        hipLaunchKernelGGL(k_bucket_sort<T>, dim3(g.nb_max), dim3(kSortThreads), 0, s, g.gp, g.shift, g.bucket_start, g.tmp, g.cell_start, g.sorted,
-                           g.pos_of, g.large_list, g.n_large, do_prof ? prof : nullptr);
+        const int t0 = bs[0]->nb_max, t1 = nbs > 1 ? bs[1]->nb_max : 0;
+        const int cnt_cap = 1 << std::max(bs[0]->shift, nbs > 1 ? bs[1]->shift : 0);
+        const size_t lds = bucket_sort_lds_bytes<T>(cnt_cap);
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[sizeof(T) == 4 ? 0 : 1]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
+            attr_set[sizeof(T) == 4 ? 0 : 1] = true;
+        }
+        // the bucket sort is the one pass that does NOT share a launch: its blocks are all resident at once (4 per CU) and
+        // finish in one round per cloud; 2 x 15 us apart against 39 us together (PCU_HIP_PAIR_SORT=1) on MI355X
+        static const bool split_sort = getenv("PCU_HIP_PAIR_SORT") == nullptr;
+        if (split_sort && nbs > 1) {
+            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0), dim3(kSortThreads), lds, s, s0, s0, t0, do_prof ? prof : nullptr, cnt_cap);
+            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t1), dim3(kSortThreads), lds, s, s1, s1, t1, do_prof ? prof : nullptr, cnt_cap);
+        } else
+        hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
         if (do_prof) {
             long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
             const double nb = h[7] > 0 ? (double)h[7] : 1.0;
             fprintf(stderr, "[bucket_sort prof] blocks %lld | mean us per block: head %.2f  zero+sync %.2f  load+rank %.2f  scan %.2f  place %.2f\n", h[7],
                     h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0, h[4] / nb / 100.0);
         }
-        if (!defer_large) index_large_pass<T>(g, nullptr, s);
-    } else {
+        if (!defer_large) index_large_pass<T>(a, b, s);
+    }
+    for (int side = 0; side < (b ? 2 : 1); ++side) {
+        GridIndex<T>& g = side ? *b : a;
+        if (g.bucketed) continue;
+        const T* d_pts = side ? pb : pa;
+        const int n = g.n, nb = (n + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
         hipLaunchKernelGGL(k_scan_reduce<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums);
         hipLaunchKernelGGL(k_scan_apply<T>, dim3(g.scan_blocks), dim3(kBlock), 0, s, g.cell_start, g.gp, g.block_sums, (unsigned)n);
@@ -257,6 +283,10 @@ static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t 
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+template <typename T>
+static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
+    return index_build_pair<T>(g, d_pts, occ, nullptr, nullptr, 0.0, s, defer_large, zero2, n_zero2);
 }
 
 // Refitted grids for unbalanced clouds (grid.h): core range of the cloud by three zooming histogram rounds, then
@@ -778,9 +808,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if ((rc = index_build(job.ridx, dr, occ, s, true, rb, (int)(sizeof(ResultBlock) / 4)))) break;
-        if ((rc = index_build(job.qidx, dq, occ_q, s, true))) break;
-        index_large_pass<T>(job.ridx, &job.qidx, s);
+        if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break;
         if (st) st->n_grid_builds += 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
@@ -850,8 +878,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call's result block: both directions' counters + the epilogue's ticket)
-    if (index_build(ix, P.dx, occ, s, s2 == s, P.rb, (int)(sizeof(ResultBlock) / 4)) || index_build(iy, P.dy, occ, s2, s2 == s)) return -1;
-    if (s2 == s) index_large_pass<T>(ix, &iy, s);
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, false, P.rb, (int)(sizeof(ResultBlock) / 4))) return -1; }
+    else if (index_build(ix, P.dx, occ, s, false, P.rb, (int)(sizeof(ResultBlock) / 4)) || index_build(iy, P.dy, occ, s2)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
@@ -1085,8 +1113,6 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
-    HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
     HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into it
     *out_ctx = c;
     return 0;
@@ -1102,7 +1128,6 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->tickets) (void)hipFree(c->tickets);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (auto& e : c->jev) if (e) (void)hipEventDestroy(e);

@@ -3,12 +3,10 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/ab_pytest.txt
-for v in default nospin fused two_streams; do
+for v in default split_sort; do
   case $v in
     default) E="" ;;
-    nospin) E="PCU_HIP_NO_SPIN=1" ;;
-    fused) E="PCU_HIP_FUSED_GRID=1" ;;
-    two_streams) E="PCU_HIP_TWO_STREAMS=1" ;;
+    split_sort) E="PCU_HIP_SPLIT_SORT=1" ;;
   esac
   echo "== $v" >> gpurun_out/ab_bench.txt
   env $E timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline >> gpurun_out/ab_bench.txt 2>&1
