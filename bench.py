@@ -87,7 +87,7 @@ def main():
     pcu.set_timing(0)
     for _ in range(args.warmup):
         pcu.chamfer_distance(x, y)
-    # Roofline input: HIP events around the main search launches (k_search*<float>, one per direction), recorded by the
+    # Roofline input: HIP events around the main search launch (k_search1_flat<float>, both directions), recorded by the
     # library on its launch stream INSIDE the timed region -- on every 4th step only, because each event is a ~6 us
     # bubble between kernels (8 events per step cost ~10 % of the step).
     KEV_EVERY = 4
@@ -127,16 +127,17 @@ def main():
         steps = max(args.steps, 1)
         qpts_per_step = 2 * n * world
         value = qpts_per_step * steps / dt
-        # dominant kernel: k_search<float,1>, one launch per direction = n queries vs n dataset points.
-        # algorithmic bytes of one launch (B_knn with k=1, s=4): 3*4*n + 3*4*n + n*(4+8) = 36 B/query
-        alg_bytes = 36.0 * n
+        # dominant kernel: k_search1_flat<float>, ONE launch for both directions = 2n queries, each against the other
+        # cloud's n points. Algorithmic bytes (B_knn with k=1, s=4): 3*4 (query) + 3*4 (its share of the
+        # dataset) + 4+8 (distance, index) = 36 B per query -> 72n B per launch
+        alg_bytes = 36.0 * 2 * n
         avg_ms = k_ms / max(k_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("k_search_f32_k1_bytes_per_launch")
+                traffic = json.load(open(tp)).get("k_search1_flat_f32_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -146,10 +147,10 @@ def main():
             "config": {"workload": f"chamfer_distance, {n}-vs-{n} fp32 U[0,1)^3 clouds, one independent pair per GPU per step, "
                                    "inputs resident in HBM, scalar results gathered once (RCCL all_gather)",
                        "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_search<float,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_search1_flat<float> (both directions in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n,
-                         "timing": f"HIP events around both main search launches of every {KEV_EVERY}th timed step"},
+                         "timing": f"HIP events around the main search launch of every {KEV_EVERY}th timed step"},
             "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
                                    "note": "3 extra steps outside the timed region, phase events on"},
             "chamfer": float(results[0]),

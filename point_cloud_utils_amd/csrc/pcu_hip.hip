@@ -350,28 +350,29 @@ constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced wh
                                         // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)
 constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
+static bool use_gather_kernels() { static const bool v = getenv("PCU_HIP_TILE") == nullptr; return v; }
+static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }
+static int grid8(int nwork, int tb) { return (((nwork + tb - 1) / tb) + 7) / 8 * 8; }       // multiple of 8: XCD-aware block map
+
+// Main (lane-per-query) pass of one direction, or -- k = 1 on open indexes -- of both directions of a two-sided call in
+// one launch (a1 / nwork1).
 template <typename T>
-static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s, bool open_index) {
+static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s, bool open_index,
+                              const SearchArgs<T>* a1 = nullptr, int nwork1 = 0) {
     if (nwork <= 0) return 0;
-    // grid = multiple of 8 (XCD-aware block map). Default: the per-lane gather kernel; PCU_HIP_TILE=1 selects the
-    // LDS-tiled kernel (one wave per block). Measured on MI355X (profiles/r01_search_kernel_ab.txt): both are
-    // instruction-issue bound at ~2-3k instructions per wave; the tile kernel issues 15x fewer vector memory
-    // instructions but more VALU/SALU/LDS bookkeeping and is slower (129 vs 83 us at 1M/k=1), so gather stays default.
-    static const bool use_gather = getenv("PCU_HIP_TILE") == nullptr;
-    static const bool use_k1 = getenv("PCU_HIP_NO_K1") == nullptr;
+    // Default: the per-lane gather kernels; PCU_HIP_TILE=1 selects the LDS-tiled kernel (one wave per block). Measured on
+    // MI355X (profiles/r01_search_kernel_ab.txt): the tile kernel issues 15x fewer vector memory instructions but more
+    // VALU/SALU/LDS bookkeeping and is slower (129 vs 83 us at 1M/k=1), so gather stays default.
+    const bool use_gather = use_gather_kernels();
     const int tb = use_gather ? kBlock : 64;
-    dim3 grid((((nwork + tb - 1) / tb) + 7) / 8 * 8), block(tb);
-    if (K == 1 && use_gather && use_k1 && open_index) {        // k = 1 on an open index: the group-wise kernel
-        static const int variant = [] { const char* e = getenv("PCU_HIP_K1"); return !e ? 0 : (strcmp(e, "early") == 0 ? 1 : (strcmp(e, "flat93") == 0 ? 2 : (strcmp(e, "rows") == 0 ? 3 : 0))); }();
-        static const bool w8 = getenv("PCU_HIP_K1_W8") != nullptr;
-        if (variant == 0 && w8 && sizeof(T) == 4) hipLaunchKernelGGL((k_search1_flat<T, false, 8>), grid, block, 0, s, a);
-        else if (variant == 0) hipLaunchKernelGGL((k_search1_flat<T, false, 4>), grid, block, 0, s, a);
-        else if (variant == 1) hipLaunchKernelGGL((k_search1_flat<T, true, 4>), grid, block, 0, s, a);
-        else if (variant == 2) hipLaunchKernelGGL((k_search1<T, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_search1<T, false>), grid, block, 0, s, a);
+    if (K == 1 && use_gather && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
+        const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
+        hipLaunchKernelGGL((k_search1_flat<T, false, 4>), dim3(g0 + g1), dim3(tb), 0, s, a, a1 ? *a1 : a, g0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (a1) return fail(PCU_HIP_ERR_RUNTIME, "internal: paired main pass without the k = 1 kernel");
+    dim3 grid(grid8(nwork, tb)), block(tb);
 #define PCU_CASE(KK) case KK: if (use_gather) hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); \
                               else hipLaunchKernelGGL((k_search_tile<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
@@ -383,11 +384,11 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     return 0;
 }
 template <typename T>
-static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s) {
+static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
     const int blocks = a.qcount_dev ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a); break;
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1); break;
     switch (K) {
         PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
@@ -493,6 +494,40 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         if (launch_search_wave<T>(KL, b, s)) return -1;
         if (st) st->n_passes += 2;
     }
+    return 0;
+}
+
+// Both directions of a two-sided call (k = 1): ONE lane-per-query launch and ONE wave-per-query launch serve both
+// (each direction keeps its own lists and counters). Falls back to two search_enqueue calls when a direction does not
+// take the k = 1 lane kernel (few queries, tile / generic kernels selected by environment).
+template <typename T>
+static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st) {
+    auto lane_k1 = [](const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0; };
+    if (!(lane_k1(j0) && lane_k1(j1) && use_gather_kernels() && use_k1_kernel())) {
+        if (search_enqueue(c, s, j0, st, /*zero_counters=*/false)) return -1;
+        return search_enqueue(c, s, j1, st, false);
+    }
+    SearchArgs<T> a[2], b[2];
+    for (int d = 0; d < 2; ++d) {
+        const SearchJob<T>& j = d ? j1 : j0;
+        const SearchScratch<T>& sc = j.sc;
+        a[d] = base_args(j, j.ridx);
+        a[d].nq = j.qidx.n; a[d].R = 1;
+        a[d].unresolved = sc.u1; a[d].n_unresolved = sc.counters + C_U1;
+        a[d].ties = sc.t1; a[d].n_ties = sc.counters + C_T1;
+        if (j.skew_check) a[d].skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
+        b[d] = base_args(j, j.ridx);
+        b[d].ties = sc.tt; b[d].n_ties = sc.counters + C_TT;
+        b[d].qlist = sc.t1; b[d].qcount_dev = sc.counters + C_T1; b[d].R = 1;            // possible ties -> total order, radius 1
+        b[d].qlist2 = sc.u1; b[d].qcount2_dev = sc.counters + C_U1; b[d].R2 = 2;         // stragglers, radius 2
+        b[d].unresolved = sc.u2; b[d].n_unresolved = sc.counters + C_U2;
+    }
+    const bool time_it = st && c->time_kernels && c->n_kev + 2 <= 8;
+    if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
+    if (launch_search_fast<T>(1, a[0], j0.qidx.n, s, true, &a[1], j1.qidx.n)) return -1;
+    if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+    if (launch_search_wave<T>(2, b[0], s, &b[1])) return -1;
+    if (st) st->n_passes += 4;
     return 0;
 }
 
@@ -886,8 +921,11 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
-    if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
-    if (two_sided && search_enqueue(c, s2, P.yx, st, false)) return -1;
+    if (two_sided && s2 == s) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
+    else {
+        if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
+        if (two_sided && search_enqueue(c, s2, P.yx, st, false)) return -1;
+    }
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[3], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[3], 0)); }   // join
     tm.mark(2);
     return 0;

@@ -327,218 +327,19 @@ __device__ __forceinline__ double dist2_k1(const Pt4<double>& q, const Pt4<doubl
 __device__ __forceinline__ float min4(float a, float b, float c, float d) { return __builtin_fminf(__builtin_fminf(__builtin_fminf(a, b), c), d); }
 __device__ __forceinline__ double min4(double a, double b, double c, double d) { return __builtin_fmin(__builtin_fmin(a, b), __builtin_fmin(c, d)); }
 
-// FLAT variant (default): after the centre row has given a first estimate, the surviving cut runs of the other eight rows
-// are written to a per-lane list in LDS ({byte offset, record count, row bound as a round-down bf16}: 8 bytes each) and
-// consumed by ONE loop per lane, with the next group's four loads issued before the current group is evaluated. The
-// lanes of a wave then walk their own lists in lock step (a wave runs max-over-lanes of the TOTAL group count instead of
-// the sum over rows of per-row maxima) and every wait on memory covers two groups. Row pruning stays adaptive (the bound
-// is re-checked, against a minimum that may be one group stale -- still a valid bound -- when a lane moves to its next
-// run); the cell cuts are those decided after the centre row.
 __device__ __forceinline__ unsigned lb_pack(float lb) { return __float_as_uint(lb) >> 16; }                  // truncation rounds a value >= 0 down
 __device__ __forceinline__ unsigned lb_pack(double lb) { const double v = lb * (1.0 - 1e-6); return __float_as_uint((float)(v < 1e38 ? v : 1e38)) >> 16; }
 template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { return (T)__uint_as_float(b << 16); }
-
-template <typename T, bool FLAT>
-__global__ __launch_bounds__(kBlock) void k_search1(const SearchArgs<T> a) {
-    const int per = (int)(gridDim.x >> 3);
-    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);       // XCD-aware block order, see k_search
-    const int t = vb * kBlock + threadIdx.x;
-    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
-    if (t >= nq) return;
-    const int qpos = a.qlist ? a.qlist[t] : t;
-    const Pt4<T> q = a.qsorted[qpos];
-    const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
-    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
-    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
-    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
-    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-
-    // Row tables: ONE 16-byte load per row fetches the starts of the run's (up to) three cells and its end,
-    // cell_start[lo .. lo+3] (only dword-aligned; entries past the run are loaded but not used), instead of two 4-byte
-    // loads for the run's ends: half the index loads, and the inner cell boundaries come for free (cell pruning below).
-    const int len = x1 - x0 + 1;                      // cells per row run: 3, 2 at a grid border (1 if Gx == 1)
-    unsigned cs0[9], cs1[9], cs2[9], cs3[9];
-    bool odd[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
-        const bool ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
-        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
-        const CellStart4 v = *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
-        odd[j] = row & 1;
-        cs0[j] = v.v[0];
-        cs1[j] = ok ? v.v[1] : v.v[0];
-        cs2[j] = ok ? v.v[2] : v.v[0];
-        cs3[j] = ok ? v.v[3] : v.v[0];
-    }
-    unsigned total = 0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) total += (len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j])) - cs0[j];
-    const bool defer = total > (a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u);      // (FLAT packs a run's record count into 16 bits)
-
-    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
-    constexpr int kG = K1Group<T>::n;       // records per group
-    const char* const base = reinterpret_cast<const char*>(a.ref);
-    T best = Limits<T>::max_v;
-    unsigned boff = 0xffffffffu;            // byte offset of the group that holds the running minimum
-    unsigned toff = 0xffffffffu;            // ... of the last group that repeated it
-    bool tie = false, tie2 = false;         // running minimum met again in another group / more than once
-    // Pruning, per lane, against the running minimum (strict '<': no tie can hide in what is skipped either):
-    //   rows   LB = (my*my) + (mz*mz)                 my / mz: rounding-safe distance to the slab of the row (0: own)
-    //   cells  LB = ((mx*mx) + (my*my)) + (mz*mz)     for the run's outer cells ccx-1 / ccx+1; the cut run stays contiguous
-    T rlb[9];
-    row_lower_bounds(g, q, ccy, ccz, rlb);
-    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
-    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
-    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
-    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
-    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;           // the run has a cell left / right of the query's
-    T my2[3], mz2[3];
-    {
-        T m;
-        my2[0] = (T)0; mz2[0] = (T)0;
-        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
-        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
-        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
-        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
-    }
-    // one group of kG records at byte offset `off`: minimum d2, then the running minimum / tie bookkeeping
-#define PCU_K1_EVAL(C0, C1, C2, C3, OFF)                                                                     \
-    {                                                                                                        \
-        const T m_ = min4(dist2_k1(q, C0), dist2_k1(q, C1), dist2_k1(q, C2), dist2_k1(q, C3));             \
-        const bool eq_ = m_ == best, lt_ = m_ < best;                                                        \
-        tie2 = !lt_ && (tie2 || (tie && eq_));                                                               \
-        tie = !lt_ && (tie || eq_);                                                                          \
-        toff = eq_ ? (OFF) : toff;                                                                           \
-        best = lt_ ? m_ : best;                                                                              \
-        boff = lt_ ? (OFF) : boff;                                                                           \
-    }
-    if (FLAT) {
-        __shared__ uint2 s_rng[8][kBlock];
-        const int tid = threadIdx.x;
-        // centre row: whole run
-        {
-            const unsigned o0 = cs0[0] * kRec;
-            const unsigned o1 = defer ? o0 : (len == 3 ? cs3[0] : (len == 2 ? cs2[0] : cs1[0])) * kRec;
-            for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
-                const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
-                const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-                PCU_K1_EVAL(c0, c1, c2, c3, off)
-            }
-        }
-        // the other rows: cut runs that survive the centre row's minimum -> this lane's list
-        int n = 0;
-#pragma unroll
-        for (int j = 1; j < 9; ++j) {
-            const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
-            const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
-            const bool cut_first = odd[j] ? cut_hi : cut_lo, cut_last = odd[j] ? cut_lo : cut_hi;
-            const unsigned s_run = cut_first ? cs1[j] : cs0[j];
-            const unsigned e_full = len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j]);
-            const unsigned e_cut = len == 3 ? cs2[j] : (len == 2 ? cs1[j] : cs0[j]);
-            const unsigned e_run = cut_last ? e_cut : e_full;
-            if (!defer && !(best < rlb[j]) && e_run > s_run) {
-                s_rng[n][tid] = make_uint2(s_run * kRec, ((e_run - s_run) << 16) | lb_pack(rlb[j]));
-                ++n;
-            }
-        }
-        int r = 0;
-        unsigned off = 0, end = 0;
-        bool live = false;
-        auto next_run = [&]() {
-            live = false;
-            while (r < n) {
-                const uint2 e = s_rng[r][tid];
-                ++r;
-                if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + (e.y >> 16) * kRec; live = true; break; }
-            }
-        };
-        next_run();
-        // Ping-pong: A is evaluated while B's four loads are in flight, and vice versa. The loads are unconditional
-        // straight-line code (a lane that has just run out of work fetches the +inf sentinel records once): loads issued
-        // under a branch would make the compiler wait for them at the join, i.e. before the older group is evaluated.
-        const unsigned sent_off = a.n_ref * kRec;
-        Pt4<T> a0, a1, a2, a3, b0, b1, b2, b3;
-        if (live) {
-            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
-            for (;;) {
-                unsigned coff = off;
-                off += (unsigned)kG * kRec;
-                if (off >= end) next_run();
-                { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); b0 = c[0]; b1 = c[1]; b2 = c[2]; b3 = c[3]; }
-                PCU_K1_EVAL(a0, a1, a2, a3, coff)
-                if (!live) break;
-                coff = off;
-                off += (unsigned)kG * kRec;
-                if (off >= end) next_run();
-                { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
-                PCU_K1_EVAL(b0, b1, b2, b3, coff)
-                if (!live) break;
-            }
-        }
-    } else
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const bool any = !defer && !(best < rlb[j]);
-        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
-        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
-        // even rows run in +x (first cell in memory = x0), odd rows in -x (first cell = x1)
-        const bool cut_first = odd[j] ? cut_hi : cut_lo, cut_last = odd[j] ? cut_lo : cut_hi;
-        const unsigned s_run = cut_first ? cs1[j] : cs0[j];
-        const unsigned e_full = len == 3 ? cs3[j] : (len == 2 ? cs2[j] : cs1[j]);
-        const unsigned e_cut = len == 3 ? cs2[j] : (len == 2 ? cs1[j] : cs0[j]);
-        const unsigned e_run = cut_last ? e_cut : e_full;
-        const unsigned o0 = s_run * kRec;
-        const unsigned o1 = any ? e_run * kRec : o0;
-        for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
-            const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
-            const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            PCU_K1_EVAL(c0, c1, c2, c3, off)
-        }
-    }
-#undef PCU_K1_EVAL
-    T bd[1] = {best};
-    int bi[1] = {0x7fffffff};
-    if (boff != 0xffffffffu) {
-        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)boff);
-        int hits = 0;
-#pragma unroll
-        for (int u = kG - 1; u >= 0; --u) {
-            const Pt4<T> cu = c[u];
-            const bool eq = dist2_k1(q, cu) == best;
-            hits += eq ? 1 : 0;
-            bi[0] = eq ? (int)cu.idx : bi[0];
-        }
-        if (hits > 1) { tie = true; tie2 = true; }
-    }
-    if (tie && !tie2) {
-        // The minimum was met exactly once more, in group `toff`. At a grid border the records behind a row's end can
-        // belong to another row of the same 27 cells, so this may be the winner itself seen twice: not a tie.
-        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)toff);
-        int hits = 0, id = 0x7fffffff;
-#pragma unroll
-        for (int u = kG - 1; u >= 0; --u) {
-            const Pt4<T> cu = c[u];
-            const bool eq = dist2_k1(q, cu) == best;
-            hits += eq ? 1 : 0;
-            id = eq ? (int)cu.idx : id;
-        }
-        if (hits == 1 && id == bi[0]) tie = false;
-    }
-    finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
-}
 
 // k = 1 main pass, flattened (the default). Same arithmetic, pruning rules and tie bookkeeping as k_search1<T, true>, laid
 // out for registers: the centre row's table is loaded and scanned first; only then are the other eight rows' tables
 // fetched (EARLY = false; one more dependent wait per wave, but their 32 registers are not live during the centre scan,
 // which brings the kernel from 93 to <= 64 VGPRs, i.e. from 5 to 8 waves per SIMD) or, with EARLY = true, right away.
-template <typename T, bool EARLY, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs<T> a) {
+template <typename T, bool EARLY>
+__device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int bid, const int nblk) {
     __shared__ uint2 s_rng[8][kBlock];
-    const int per = (int)(gridDim.x >> 3);
-    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);       // XCD-aware block order, see k_search
+    const int per = nblk >> 3;
+    const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search (nblk and the side's first block: multiples of 8)
     const int t = vb * kBlock + threadIdx.x;
     const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
     if (t >= nq) return;
@@ -696,6 +497,14 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs<
     const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
     finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
+// Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
+template <typename T, bool EARLY, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs<T> a0, const SearchArgs<T> a1, int nb0) {
+    // (two inlined copies of the body under a uniform branch: selecting between the two argument structs by reference
+    // makes the compiler copy the chosen one to scratch)
+    if ((int)blockIdx.x < nb0) search1_flat_body<T, EARLY>(a0, (int)blockIdx.x, nb0);
+    else search1_flat_body<T, EARLY>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
 
 // -------------------------------------------------------------------------------------------------------
 // Main pass, LDS-tiled (the default): ONE WAVE = 64 consecutive queries of the cell-ordered query cloud, i.e. a
@@ -837,17 +646,23 @@ template <typename T>
 __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d < d2 || (d == d2 && id < id2); }
 
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a) {
+__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * kBlock) >> 6;
-    const int nq1 = a.qcount_dev ? *a.qcount_dev : a.nq;
-    const int nq = nq1 + (a.qlist2 ? *a.qcount2_dev : 0);
-    const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (wave == 0 && lane == 0) *a.skew_flag = 1; return; }
-    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int kreq = a.kreq;
-    for (int w = wave; w < nq; w += nwaves) {
+    // work items: job 0's list(s), then (two-sided calls) job 1's
+    int total0 = (a0.qcount_dev ? *a0.qcount_dev : a0.nq) + (a0.qlist2 ? *a0.qcount2_dev : 0);
+    int total1 = njobs > 1 ? (a1.qcount_dev ? *a1.qcount_dev : a1.nq) + (a1.qlist2 ? *a1.qcount2_dev : 0) : 0;
+    if (a0.skew_limit > 0.f && (float)a0.gp->sumsq > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
+    if (njobs > 1 && a1.skew_limit > 0.f && (float)a1.gp->sumsq > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
+    for (int wg = wave; wg < total0 + total1; wg += nwaves) {
+        const bool job1 = wg >= total0;
+        const SearchArgs<T>& a = job1 ? a1 : a0;
+        const int w = job1 ? wg - total0 : wg;
+        const int nq1 = a.qcount_dev ? *a.qcount_dev : a.nq;
+        const GridParams<T>& g = *a.gp;
+        const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+        const int kreq = a.kreq;
         const bool second = w >= nq1;
         const int R = second ? a.R2 : a.R;
         const int qpos = second ? a.qlist2[w - nq1] : (a.qlist ? a.qlist[w] : w);

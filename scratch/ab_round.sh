@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/ab_pytest.txt
-for v in default split_sort; do
+for v in default; do
   case $v in
     default) E="" ;;
     split_sort) E="PCU_HIP_SPLIT_SORT=1" ;;
@@ -12,6 +12,7 @@ for v in default split_sort; do
   env $E timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline >> gpurun_out/ab_bench.txt 2>&1
 done
 timeout 600 python scratch/skew.py > gpurun_out/ab_skew.txt 2>&1
+
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/ab_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/ab_trace.log 2>&1
 cd $GRAFT_REPO_ROOT
