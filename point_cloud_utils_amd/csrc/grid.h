@@ -5,12 +5,14 @@
 // the cloud into snake (boustrophedon) grid-cell order. The grid only decides which candidates a query evaluates; it has
 // no influence on results, which depend only on the distance arithmetic in search.h.
 //
-// Pipeline (all on one stream, no host round trip; grid shape lives in device memory):
-//   k_bbox_partial 256 blocks   per-block bbox partials (shuffle reduce, no atomics) + zero-fill of the cell counters
-//   k_make_grid    1 block      fold partials; bbox -> cell edge h, cell counts G (targets `occupancy` points per cell)
-//   k_count       1 pt/lane     cell id + rank-in-cell via returning atomicAdd on the cell counter
-//   k_scan_*      2 launches    exclusive prefix sum of the counters -> cell_start
-//   k_scatter     1 pt/lane     sorted[cell_start[cell] + rank] = {x,y,z,row}
+// Pipeline (all on one stream, no host round trip; grid shape lives in device memory; both clouds of a call share the
+// launches of every pass except the bucket sort):
+//   k_bbox_partial   256 blocks per cloud   bbox partials (shuffle reduce, no atomics) + zero-fill of the cell counters
+//   k_make_grid      1 block per cloud      fold partials; bbox -> cell edge h, cell counts G (`occupancy` points per cell)
+//   bucketed build (default, "bucketed build" below): k_bucket_count, k_bucket_scatter, k_bucket_sort, k_bucket_large --
+//       a two-level counting sort on the cell id whose per-point atomics are LDS atomics
+//   atomic build (tiny clouds, refitted / very coarse grids, PCU_HIP_INDEX=atomic):
+//       k_count (cell id + rank-in-cell by one returning device-scope atomicAdd per point), k_scan_reduce/_apply, k_scatter
 #pragma once
 #include "pcu_types.h"
 
@@ -345,15 +347,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
 //                     slice of the bucket                                    [~120k global atomics instead of 1M]
 //   k_bucket_scatter  same blocks: prefix of the bucket totals, LDS rank inside (block, bucket), records written into
 //                     `tmp` grouped by bucket (runs of ~8 records)
-//   k_bucket_sort     one 1024-thread block per bucket: LDS histogram over the bucket's cells, scan -> cell_start,
-//                     records written to their final slot in `sorted` (the bucket's 32-64 KB window: L2 merges lines)
+//   k_bucket_sort     one 512-thread block per bucket: LDS histogram over the bucket's cells, scan -> cell_start; the
+//                     bucket's records, parked in LDS, are permuted in place and leave as one coalesced copy
 //   k_bucket_large    buckets holding more than kLargeBucket points (clusters, surfaces tangent to a row of cells, a far
 //                     outlier) are not sorted by one block: k_bucket_scatter takes their per-cell ranks with the
 //                     returning global atomic of the old scheme (wave-aggregated when a whole wave hits one cell),
 //                     k_bucket_sort only scans their cell counters, and this grid-strided kernel places the records.
 //                     It exits at once when there is no such bucket.
 // Any valid cell order gives the same search results; the order inside a cell is arbitrary in both builds.
-constexpr int kBkThreads = 1024;                    // 16 waves per block: the passes are latency-bound, one block per CU
+constexpr int kBkThreads = 1024;                    // 16 waves per block: the passes are latency-bound
 constexpr int kBkPts = 4;                           // points per thread of the bucket passes
 constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
 constexpr int kBkMaxBuckets = 4096;

@@ -296,20 +296,32 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// Main pass for k = 1 (Chamfer / Hausdorff / k_nearest_neighbors(k=1)): same lane-per-query scan as k_search, on an
-// instruction diet. k_search<T,1> is VALU-issue bound (profiles/r01_pmc.txt: ~2.4k VALU instructions per wave, 4 cycles
-// each on a 16-lane SIMD = the kernel's whole duration), ~15 instructions per candidate. Here
+// Main pass for k = 1 (Chamfer / Hausdorff / k_nearest_neighbors(k=1)): k_search1_flat, the same lane-per-query scan as
+// k_search<T,1> re-built around what bounded it (profiles/r01_pmc.txt: 2,365 VALU instructions per wave, VALU pipes 96 %
+// busy, 108 gathered candidate slots per lane):
 //   * a row is consumed in groups of 4 records from its first record on; the last group may run up to 3 records past
 //     the row's end. Those are real dataset points of the cells that follow in snake order (or the +inf sentinels behind
 //     the last record), so offering them is harmless and no slot needs masking or a select on its address. (At a grid
-//     border the records that follow can belong to another row of the same 27 cells: a point seen twice looks like a
-//     tie with itself and merely sends the query through the tie pass.)
+//     border the records that follow can belong to another row of the same 27 cells: a winner seen twice is recognised,
+//     see the end of the kernel.)
 //   * the (x,y) differences, squares of a record go through the packed-fp32 pipe (v_pk_add_f32 / v_pk_mul_f32: IEEE
 //     add and mul, no FMA -- bit-identical to the scalar sequence);
 //   * only the running minimum d2 and the *group* it came from are tracked (v_min3 + one compare + two selects per 4
 //     candidates instead of a compare and two selects per candidate); the winning record is identified afterwards by
 //     re-evaluating that one group. An equal minimum met in another group, or twice inside the winning group, flags a
-//     possible tie exactly as before (re-resolved by the wave-per-query pass under the total order).
+//     possible tie (re-resolved by the wave-per-query pass under the total order);
+//   * rows and the outer cells of a row's run are pruned per lane against the running minimum, with lower bounds computed
+//     in the same rounding-monotone arithmetic as the certification (strict '<': no tie can hide in what is skipped):
+//       rows   LB = (my*my) + (mz*mz)                 my / mz: distance to the slab of the row (0: own row)
+//       cells  LB = ((mx*mx) + (my*my)) + (mz*mz)     for the cells ccx-1 / ccx+1 of a run; the cut run stays contiguous
+//     A skipped lane issues no loads: this saves gathered bytes (the L1/texture path is the co-bottleneck);
+//   * after the centre row has given a first estimate, the surviving cut runs of the other eight rows are written to a
+//     per-lane list in LDS ({byte offset, record count, row bound as a round-down bf16}: 8 bytes each) and consumed by ONE
+//     loop per lane, with the next group's four loads issued before the current group is evaluated. The lanes of a wave
+//     walk their own lists in lock step (a wave runs max-over-lanes of the TOTAL group count instead of the sum over rows
+//     of per-row maxima) and every wait on memory covers two groups. Row pruning stays adaptive (the bound is re-checked,
+//     against a minimum that may be one group stale -- still a valid bound -- when a lane moves to its next run); the cell
+//     cuts are those decided after the centre row.
 // Only for open indexes (closed sub-box levels have no sentinel behind their last record).
 template <typename T> struct K1Group { static constexpr int n = 4; };     // records per group (8 measured slower: more bytes gathered past the row ends)
 __device__ __forceinline__ float min2(float a, float b) { return __builtin_fminf(a, b); }
@@ -331,10 +343,9 @@ __device__ __forceinline__ unsigned lb_pack(float lb) { return __float_as_uint(l
 __device__ __forceinline__ unsigned lb_pack(double lb) { const double v = lb * (1.0 - 1e-6); return __float_as_uint((float)(v < 1e38 ? v : 1e38)) >> 16; }
 template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { return (T)__uint_as_float(b << 16); }
 
-// k = 1 main pass, flattened (the default). Same arithmetic, pruning rules and tie bookkeeping as k_search1<T, true>, laid
-// out for registers: the centre row's table is loaded and scanned first; only then are the other eight rows' tables
-// fetched (EARLY = false; one more dependent wait per wave, but their 32 registers are not live during the centre scan,
-// which brings the kernel from 93 to <= 64 VGPRs, i.e. from 5 to 8 waves per SIMD) or, with EARLY = true, right away.
+// Register layout: the centre row's table is loaded and scanned first; only then are the other eight rows' tables fetched
+// (EARLY = false: one more dependent wait per wave, but their 32 registers are not live during the centre scan: 68 VGPRs
+// instead of 93, 7 waves per SIMD instead of 5). EARLY = true fetches them right away (79 VGPRs; measured equal).
 template <typename T, bool EARLY>
 __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int bid, const int nblk) {
     __shared__ uint2 s_rng[8][kBlock];
