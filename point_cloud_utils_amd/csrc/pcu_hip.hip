@@ -367,7 +367,8 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     const int tb = use_gather ? kBlock : 64;
     if (K == 1 && use_gather && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
-        hipLaunchKernelGGL((k_search1_flat<T, false, 4>), dim3(g0 + g1), dim3(tb), 0, s, a, a1 ? *a1 : a, g0);
+        SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
+        hipLaunchKernelGGL((k_search1_flat<T, false, 4>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
         HIP_TRY(hipGetLastError());
         return 0;
     }

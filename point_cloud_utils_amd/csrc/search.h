@@ -509,12 +509,13 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
+template <typename T> struct SearchArgs2 { SearchArgs<T> a[2]; };
 template <typename T, bool EARLY, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs<T> a0, const SearchArgs<T> a1, int nb0) {
-    // (two inlined copies of the body under a uniform branch: selecting between the two argument structs by reference
-    // makes the compiler copy the chosen one to scratch)
-    if ((int)blockIdx.x < nb0) search1_flat_body<T, EARLY>(a0, (int)blockIdx.x, nb0);
-    else search1_flat_body<T, EARLY>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+__global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2<T> p, int nb0) {
+    // (the side's arguments are read through an index into the kernel-argument segment; selecting between two by-value
+    // structs by reference makes the compiler copy the chosen one to scratch)
+    const int side = (int)blockIdx.x >= nb0 ? 1 : 0;
+    search1_flat_body<T, EARLY>(p.a[side], side ? (int)blockIdx.x - nb0 : (int)blockIdx.x, side ? (int)gridDim.x - nb0 : nb0);
 }
 
 // -------------------------------------------------------------------------------------------------------
