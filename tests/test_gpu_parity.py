@@ -340,3 +340,55 @@ def test_dense_slab_bucketed_index(pcu, oracle_kind, dtype):
     assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
     assert abs(float(ch) - float(ch0)) <= (1e-4 if dtype == np.float32 else 1e-6) * float(ch0)
     assert pcu.hausdorff_distance(q, r, return_index=True) == oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
+
+
+def _fuzz_cloud(rng, n, dist, dtype):
+    if dist == "uniform": a = rng.random((n, 3))
+    elif dist == "plane": a = rng.random((n, 3)); a[:, 2] = 0.25
+    elif dist == "line": a = np.zeros((n, 3)); a[:, 0] = rng.random(n)
+    elif dist == "clusters": c = rng.random((8, 3)); a = c[rng.integers(0, 8, n)] + rng.normal(0, 0.003, (n, 3))
+    elif dist == "dups": b = rng.random((max(n // 3, 1), 3)); a = b[rng.integers(0, b.shape[0], n)]
+    elif dist == "lattice": a = rng.integers(0, 12, (n, 3)).astype(np.float64)
+    elif dist == "offset": a = rng.random((n, 3)) * 1e-3 + 1000.0
+    elif dist == "aniso": a = rng.random((n, 3)) * [1000.0, 1.0, 0.001]
+    else: v = rng.normal(size=(n, 3)); a = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)     # sphere surface
+    return np.ascontiguousarray(a.astype(dtype))
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_randomised_sweep(pcu, oracle_kind, case):
+    """Random sizes (1 .. 300k), k, dtypes and point distributions -- planes, lines, clusters, duplicated points, integer
+    lattices (exact ties everywhere), far-offset and anisotropic clouds, surfaces -- against the oracle: indices and
+    distance bits equal, Hausdorff tuple equal, Chamfer correspondences equal (scratch/fuzz.py runs longer sweeps)."""
+    dists = ["uniform", "plane", "line", "clusters", "dups", "lattice", "offset", "aniso", "sphere"]
+    rng = np.random.default_rng(4200 + case)
+    dtype = np.float32 if case % 3 else np.float64
+    hi = 300000 if case % 2 else 3000
+    n, m = int(rng.integers(1, hi)), int(rng.integers(1, hi))
+    k = min(int(rng.choice([1, 1, 2, 5, 16])), m)
+    q, r = _fuzz_cloud(rng, n, dists[case % 9], dtype), _fuzz_cloud(rng, m, dists[(case * 5 + 3) % 9], dtype)
+    d, c = pcu.k_nearest_neighbors(q, r, k)
+    d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+    assert np.array_equal(c, c0), (n, m, k, pcu.last_stats())
+    assert np.array_equal(d.view(np.uint8), d0.view(np.uint8))
+    assert pcu.hausdorff_distance(q, r, return_index=True) == oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
+    ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch) - float(ch0)) <= (1e-4 if dtype == np.float32 else 1e-6) * abs(float(ch0)) + 1e-30
+
+
+def test_timing_is_opt_in(pcu):
+    """The ms_* fields of the statistics are only filled when timing is switched on (HIP events cost pipeline bubbles)."""
+    a, b = cloud(5, 40000, np.float32), cloud(6, 40000, np.float32)
+    old = pcu.set_timing(0)
+    try:
+        pcu.chamfer_distance(a, b)
+        st = pcu.last_stats()
+        assert st["ms_total"] == 0.0 and st["n_kernel_search"] == 0 and st["n_queries"] == 80000
+        pcu.set_timing(2)
+        pcu.chamfer_distance(a, b)
+        st = pcu.last_stats()
+        assert st["ms_total"] > 0.0 and st["ms_index"] > 0.0 and st["n_kernel_search"] >= 1 and st["ms_kernel_search"] > 0.0
+    finally:
+        pcu.set_timing(old)
