@@ -149,6 +149,9 @@ def main():
                        "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_search1_flat<float> (both directions in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         "whole_op": {"alg_bytes_per_step": 48.0 * n * world, "achieved_GBps": 48.0 * n * world / (dt / steps) / 1e9,
+                                      "note": "SURVEY 8d: Chamfer p=2 without indices = 2*3*4*(N+M) bytes; all launches of the step + host"},
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n,
                          "timing": f"HIP events around the main search launch of every {KEV_EVERY}th timed step"},
             "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
