@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import Stats, set_cell_occupancy, device_count  # noqa: F401
 
 __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_distance", "chamfer_distance",
-           "last_stats", "set_timing", "set_cell_occupancy", "device_count"]
+           "last_stats", "set_timing", "set_cell_occupancy", "device_count", "DatasetIndex"]
 
 _last_stats = [None]      # the Stats struct of the most recent call (turned into a dict on demand)
 # PCU_HIP_NO_TIE_ORDER=1: skip the kd-tree tie-order resolver (exact ties then ordered by (d2, row)); for experiments.
@@ -324,3 +324,88 @@ def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10)
     if return_index:
         return cham_dist, cxy, cyx
     return cham_dist
+
+
+class DatasetIndex:
+    """A dataset kept on the GPU together with its search index (not in the reference API, which rebuilds its kd-tree on
+    every call -- three times, src/point_cloud_distance.cpp:41-42): build once, query many times.
+
+        index = pcu.DatasetIndex(dataset_points, k_hint=8)
+        dists, corrs = index.k_nearest_neighbors(query_points, 8)       # same results as pcu.k_nearest_neighbors
+
+    `dataset_points`: (m, 3) float32 / float64, numpy or CUDA/HIP torch tensor (copied; the caller's array can go away).
+    `k_hint` sizes the grid cells for the k that will mostly be asked for; any 1 <= k <= 127 is answered exactly.
+    Queries must have the dataset's dtype. The index lives on one GPU; call close() (or use `with`) to free it."""
+
+    def __init__(self, dataset_points, k_hint=1):
+        da = _dtype_name(dataset_points)
+        if da not in ("float32", "float64"):
+            raise ValueError(f"Invalid scalar type ({da}) for argument 'dataset_points'. Expected one of ['float32', 'float64'].")
+        sh = _shape2(dataset_points)
+        if sh[0] == 0 or sh[1] != 3:
+            raise ValueError(f"dataset_points must have shape (m, 3) with m > 0. Got dataset_points.shape = ({sh[0]}, {sh[1]}).")
+        d = _Dev(dataset_points, dataset_points)
+        self._suffix, self._np_dtype, self._torch, self._device = d.suffix, d.np_dtype, d.torch, d.device
+        h = ctypes.c_void_p()
+        rc = _fn("index_create", d.suffix)(d.ctx, d.pa, int(d.a.shape[0]), int(k_hint), d.flags, d.stream, ctypes.byref(h))
+        if rc:
+            _lib.check(rc)
+        self._h = h
+        self.num_points = int(d.a.shape[0])
+
+    def k_nearest_neighbors(self, query_points, k, squared_distances=False, max_points_per_leaf=10):
+        """See point_cloud_utils_amd.k_nearest_neighbors; the dataset is the indexed one."""
+        if self._h is None:
+            raise ValueError("the index has been closed")
+        k = int(k)
+        if k <= 0:
+            raise ValueError(f"Invalid value for k ({k}) must be greater than 0.")
+        dq = _dtype_name(query_points)
+        want = "float32" if self._suffix == "f32" else "float64"
+        if dq not in ("float32", "float64"):
+            raise ValueError(f"Invalid scalar type ({dq}) for argument 'query_points'. Expected one of ['float32', 'float64'].")
+        if dq != want:
+            raise ValueError(f"Invalid scalar type ({dq}) for argument 'query_points'. Expected it to match the indexed dataset which is of type {want}.")
+        sq = _shape2(query_points)
+        if sq[0] == 0:
+            raise ValueError(_KNN_ZERO.format(sq[0], sq[1], self.num_points, 3))
+        if sq[1] != 3:
+            raise ValueError(_KNN_DIM.format(sq[0], sq[1], self.num_points, 3))
+        d = _Dev(query_points, query_points)
+        if d.torch and d.device != self._device:
+            raise ValueError("query tensor and index live on different devices")
+        n = int(d.a.shape[0])
+        dists = d.empty((n, k), "T")
+        corrs = d.empty((n, k), "i64")
+        st = Stats()
+        flags = d.flags | (_lib.SQUARED if squared_distances else 0)
+        rc = _fn("index_knn", d.suffix)(d.ctx, self._h, d.pa, n, k, int(max_points_per_leaf), _Dev.ptr(dists), _Dev.ptr(corrs),
+                                        flags, d.stream, ctypes.addressof(st))
+        if rc:
+            _lib.check(rc)
+        _record(st)
+        if k == 1 or n == 1:
+            return dists.reshape(-1), corrs.reshape(-1)
+        if not d.torch:
+            q = np.asarray(query_points)
+            if q.flags.f_contiguous and not q.flags.c_contiguous:
+                dists = np.asfortranarray(dists)
+        return dists, corrs
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.lib().pcu_hip_index_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -79,6 +79,12 @@ def lib():
             getattr(L, "pcu_hip_chamfer_" + suf).argtypes = [vp, vp, i64, vp, i64, ctypes.c_double, ci, vp, vp, vp, u, vp, vp]
         for suf in ("f32", "f64"):
             getattr(L, "pcu_hip_debug_kd_tree_" + suf).argtypes = [vp, vp, i64, ci, vp, vp]
+            getattr(L, "pcu_hip_index_create_" + suf).argtypes = [vp, vp, i64, ci, u, vp, ctypes.POINTER(ctypes.c_void_p)]
+            getattr(L, "pcu_hip_index_knn_" + suf).argtypes = [vp, vp, vp, i64, ci, ci, vp, vp, u, vp, vp]
+        L.pcu_hip_index_size.restype = ctypes.c_int64
+        L.pcu_hip_index_size.argtypes = [vp]
+        L.pcu_hip_index_destroy.argtypes = [vp]
+        L.pcu_hip_index_destroy.restype = None
         _lib = L
     return _lib
 

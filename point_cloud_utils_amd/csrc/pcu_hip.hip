@@ -806,10 +806,29 @@ static int stage_in(Arena& ar, const T* p, int64_t n, bool on_dev, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------ knn
+// A dataset kept on the GPU together with its grid index (pcu_hip_index_*): memory owned by the object, not by a call's arena.
+struct pcu_hip_index {
+    int elem_size = 0;            // 4: float, 8: double
+    int device = 0;
+    int64_t n = 0;
+    double occ = 0;
+    void* pts = nullptr;          // (n,3) device copy of the dataset
+    void* mem = nullptr;          // block holding the index buffers
+    GridIndex<float> g32; GridIndex<double> g64;
+};
+template <typename T> static const GridIndex<T>& index_grid(const pcu_hip_index* p);
+template <> const GridIndex<float>& index_grid<float>(const pcu_hip_index* p) { return p->g32; }
+template <> const GridIndex<double>& index_grid<double>(const pcu_hip_index* p) { return p->g64; }
+
 template <typename T>
 static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
-                    T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st) {
+                    T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx = nullptr) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (pidx) {
+        if (pidx->elem_size != (int)sizeof(T)) return fail(PCU_HIP_ERR_INVALID, "the index was built for the other floating-point type");
+        if (pidx->device != c->device) return fail(PCU_HIP_ERR_INVALID, "the index lives on device %d, the context on device %d", pidx->device, c->device);
+        nr = pidx->n;
+    }
     if (k <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid value for k (%d) must be greater than 0.", k);
     if (validate_sizes(nq, nr, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
     if (k > kMaxK) return fail(PCU_HIP_ERR_INVALID, "k = %d > %d is not supported by the gfx950 path yet", k, kMaxK);
@@ -817,11 +836,11 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
-    const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k);
+    const double occ = pidx ? pidx->occ : (c->occupancy > 0 ? c->occupancy : default_occupancy(k));
     const double occ_q = 2.0;
-    size_t need = index_bytes<T>(nr, occ) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
+    size_t need = (pidx ? 0 : index_bytes<T>(nr, occ)) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
                   align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);     // cell-ordered results
-    if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + align_up((size_t)nr * 3 * sizeof(T), 256) +
+    if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + (pidx ? 0 : align_up((size_t)nr * 3 * sizeof(T), 256)) +
                          align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);
     if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c};
@@ -830,11 +849,13 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     do {
         const T *dq, *dr;
         if ((rc = stage_in(ar, query, nq, on_dev, s, &dq))) break;
-        if ((rc = stage_in(ar, dataset, nr, on_dev, s, &dr))) break;
+        if (pidx) dr = static_cast<const T*>(pidx->pts);
+        else if ((rc = stage_in(ar, dataset, nr, on_dev, s, &dr))) break;
         T* dd = out_d; long long* di = (long long*)out_i;
         if (!on_dev) { if ((rc = aalloc(ar, &dd, (size_t)nq * k))) break; if ((rc = aalloc(ar, &di, (size_t)nq * k))) break; }
         SearchJob<T> job;
-        if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
+        if (pidx) job.ridx = index_grid<T>(pidx);
+        else if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
         if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/true))) break;
         ResultBlock* rb = nullptr;
         if ((rc = aalloc(ar, &rb, 1))) break;
@@ -844,8 +865,9 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break;
-        if (st) st->n_grid_builds += 2;
+        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break; }
+        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break;
+        if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
         if ((rc = unpermute_enqueue(s, job, dd, di))) break;          // optimistic: redone below if stragglers / ties remain
@@ -1101,6 +1123,54 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ persistent index
+template <typename T> static GridIndex<T>& index_grid_mut(pcu_hip_index* p);
+template <> GridIndex<float>& index_grid_mut<float>(pcu_hip_index* p) { return p->g32; }
+template <> GridIndex<double>& index_grid_mut<double>(pcu_hip_index* p) { return p->g64; }
+
+static void index_free(pcu_hip_index* p) {
+    if (!p) return;
+    if (p->pts) (void)hipFree(p->pts);
+    if (p->mem) (void)hipFree(p->mem);
+    delete p;
+}
+template <typename T>
+static int index_create_impl(pcu_hip_ctx* c, const T* dataset, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
+    if (!c || !out) return fail(PCU_HIP_ERR_INVALID, "null context / output");
+    *out = nullptr;
+    if (nr <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid input set with zero elements: dataset_points must have shape (m, 3). Got dataset_points.shape = (%lld, 3).", (long long)nr);
+    if (nr > 0x07fffff0ll) return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^27-16 rows are not supported");
+    if (k_hint <= 0) k_hint = 1;
+    if (k_hint > kMaxK) k_hint = kMaxK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    pcu_hip_index* p = new pcu_hip_index();
+    p->elem_size = (int)sizeof(T); p->device = c->device; p->n = nr;
+    p->occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k_hint);
+    int rc = 0;
+    do {
+        if (hipMalloc(&p->pts, (size_t)nr * 3 * sizeof(T)) != hipSuccess) { rc = fail(PCU_HIP_ERR_RUNTIME, "out of device memory for the dataset copy"); break; }
+        if (hipMemcpyAsync(p->pts, dataset, (size_t)nr * 3 * sizeof(T), (flags & PCU_HIP_PTRS_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s) != hipSuccess) {
+            rc = fail(PCU_HIP_ERR_RUNTIME, "copy of the dataset failed"); break;
+        }
+        const size_t bytes = index_bytes<T>(nr, p->occ) + 4096;
+        if (hipMalloc(&p->mem, bytes) != hipSuccess) { rc = fail(PCU_HIP_ERR_RUNTIME, "out of device memory for the index"); break; }
+        pcu_hip_ctx holder;                         // only its arena fields are used: a bump allocator over the index's own block
+        holder.device = c->device; holder.arena = static_cast<char*>(p->mem); holder.arena_cap = bytes; holder.arena_off = 0;
+        Arena ar{&holder};
+        GridIndex<T>& g = index_grid_mut<T>(p);
+        if (index_alloc(ar, g, nr, p->occ) || !holder.extra.empty()) {
+            for (void* q : holder.extra) (void)hipFree(q);
+            rc = fail(PCU_HIP_ERR_RUNTIME, "internal: index block too small"); break;
+        }
+        if ((rc = index_build<T>(g, static_cast<const T*>(p->pts), p->occ, s))) break;
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(PCU_HIP_ERR_RUNTIME, "index build failed"); break; }
+    } while (0);
+    if (rc) { index_free(p); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
+    *out = p;
+    return 0;
+}
+
 // Diagnostic hook for tests: builds the nanoflann-faithful kd-tree of `pts` on the GPU and returns its
 // permutation (vAcc) and node count, so the tree itself can be compared with the oracle's.
 template <typename T>
@@ -1196,5 +1266,29 @@ int pcu_hip_chamfer_f64(pcu_hip_ctx* c, const double* x, int64_t nx, const doubl
 
 int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
 int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
+
+int pcu_hip_index_create_f32(pcu_hip_ctx* c, const float* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
+    return index_create_impl<float>(c, r, nr, k_hint, flags, stream, out);
+}
+int pcu_hip_index_create_f64(pcu_hip_ctx* c, const double* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
+    return index_create_impl<double>(c, r, nr, k_hint, flags, stream, out);
+}
+int pcu_hip_index_knn_f32(pcu_hip_ctx* c, const pcu_hip_index* ix, const float* q, int64_t nq, int k, int max_leaf, float* od, int64_t* oi,
+                          unsigned flags, void* stream, pcu_hip_stats* st) {
+    if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
+    return knn_impl<float>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
+}
+int pcu_hip_index_knn_f64(pcu_hip_ctx* c, const pcu_hip_index* ix, const double* q, int64_t nq, int k, int max_leaf, double* od, int64_t* oi,
+                          unsigned flags, void* stream, pcu_hip_stats* st) {
+    if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
+    return knn_impl<double>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
+}
+int64_t pcu_hip_index_size(const pcu_hip_index* ix) { return ix ? ix->n : 0; }
+void pcu_hip_index_destroy(pcu_hip_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    index_free(ix);
+}
 
 }  // extern "C"

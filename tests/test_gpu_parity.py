@@ -392,3 +392,35 @@ def test_timing_is_opt_in(pcu):
         assert st["ms_total"] > 0.0 and st["ms_index"] > 0.0 and st["n_kernel_search"] >= 1 and st["ms_kernel_search"] > 0.0
     finally:
         pcu.set_timing(old)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dataset_index_matches_one_shot_calls(pcu, oracle_kind, dtype):
+    """DatasetIndex (dataset indexed once, kept on the GPU): every query batch gets exactly what k_nearest_neighbors
+    returns -- oracle parity included -- for several k, for duplicated data (tie order through the resolver) and for an
+    unbalanced dataset (refit path run per call on top of the persistent index)."""
+    r = cloud(31, 120000, dtype)
+    with pcu.DatasetIndex(r, k_hint=4) as index:
+        assert index.num_points == 120000
+        for seed, n, k in ((32, 50000, 1), (33, 70000, 4), (34, 900, 16)):
+            q = cloud(seed, n, dtype)
+            d, c = index.k_nearest_neighbors(q, k)
+            assert pcu.last_stats()["n_grid_builds"] == 1          # only the queries were indexed
+            d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+            _assert_knn(pcu, d, c, d0, c0)
+        d, c = index.k_nearest_neighbors(r[:40000], 3, squared_distances=True)      # self-queries: exact zero distances, ties
+        d0, c0 = oracle.k_nearest_neighbors(r[:40000], r, 3, squared_distances=True, kind=oracle_kind)
+        _assert_knn(pcu, d, c, d0, c0)
+    with pytest.raises(ValueError, match="closed"):
+        index.k_nearest_neighbors(r[:10], 1)
+    rng = np.random.default_rng(35)
+    r2 = np.concatenate([rng.random((60000, 3)), rng.normal(0.5, 0.002, (20000, 3))]).astype(dtype)
+    r2[0] = [500.0, -300.0, 100.0]
+    index = pcu.DatasetIndex(r2)
+    q = np.concatenate([rng.random((30000, 3)), rng.normal(0.5, 0.002, (30000, 3))]).astype(dtype)
+    d, c = index.k_nearest_neighbors(q, 2)
+    d0, c0 = oracle.k_nearest_neighbors(q, r2, 2, kind=oracle_kind)
+    _assert_knn(pcu, d, c, d0, c0)
+    with pytest.raises(ValueError, match="match the indexed dataset"):
+        index.k_nearest_neighbors(q.astype(np.float64 if dtype == np.float32 else np.float32), 1)
+    index.close()
