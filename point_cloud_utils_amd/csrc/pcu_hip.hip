@@ -711,7 +711,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     if (n_left == 0) {
         if (st) st->n_tie_true += hc[C_TT];
         j.n_tt = hc[C_TT];
-        if (hc[C_TT] > 0 && j.tie_order) { if (tie_order_resolve(c, ar, s, j, hc[C_TT], st)) return -1; return 1; }
+        if (hc[C_TT] > 0 && j.tie_order) { if (tie_order_resolve(c, ar, s, j, hc[C_TT], st)) return -1; return redone ? 1 : 2; }   // 2: only the rows in the tie list changed
         return redone ? 1 : 0;
     }
     const int KL = std::max(2, pow2_at_least(j.k + 1));
@@ -876,6 +876,12 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         HIP_TRY(hipStreamSynchronize(s));
         if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
         if (rc == 1) { if ((rc = unpermute_enqueue(s, job, dd, di))) break; tm.mark(2); }
+        else if (rc == 2) {       // the resolver rewrote only the tied queries' rows: restore just those
+            hipLaunchKernelGGL(k_unpermute_rows<T>, dim3((unsigned)((job.n_tt * (long long)k + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                               job.sc.tt, job.n_tt, job.qidx.sorted, job.out_d, job.out_i, dd, di, k);
+            HIP_TRY(hipGetLastError());
+            tm.mark(2);
+        }
         rc = 0;
         if (!on_dev) {
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
@@ -981,7 +987,7 @@ static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P
     if (r1 < 0) return r1;
     int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1]) : 0;
     if (r2 < 0) return r2;
-    return (r1 | r2) ? 1 : 0;
+    return (r1 | r2) ? 1 : 0;       // (2 = "only tied rows changed" matters to k_nearest_neighbors only)
 }
 
 // Arg-max epilogue of one or both directions (+ copy of the result block to pinned host memory): one launch.

@@ -277,8 +277,27 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const bool defer = total > a.lane_max_cand;
     T rlb[9];
     row_lower_bounds(g, q, ccy, ccz, rlb);
+    // K > 1: accepted candidates are first parked in a small per-lane buffer in LDS and inserted in bursts. The sorted
+    // insertion is K-wide predicated code that the whole wave executes whenever ANY lane accepts a candidate -- early in a
+    // scan that is every candidate (k = 16: 64 of the 78 VALU instructions per candidate step). Parked candidates go through
+    // the very same offer() later, against a k-th best that can only have become smaller, so results and tie flags are
+    // unchanged; a wave now runs the insertion max-over-lanes-of-the-buffer-fill times per burst instead of once per step.
+    constexpr int kBuf = K > 1 ? 12 : 1;
+    __shared__ T s_bd[kBuf][kBlock];
+    __shared__ int s_bi[kBuf][kBlock];
+    const int tid = threadIdx.x;
+    int cnt = 0;
+    auto flush = [&]() {
+        int mx = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        for (int i = 0; i < mx; ++i)
+            if (i < cnt) offer<T, K>(s_bd[i][tid], s_bi[i][tid], bd, bi, tie);
+        cnt = 0;
+    };
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
+        if (K > 1 && __any(cnt >= kBuf / 2)) flush();        // (also gives the row pruning below a fresher k-th best)
         const unsigned e = (defer || bd[K - 1] < rlb[j]) ? rs[j] : re[j];
         for (unsigned p = rs[j]; p < e; p += kGroup) {
             Pt4<T> c[kGroup];
@@ -287,10 +306,21 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
                 const unsigned idx = (p + u < e) ? p + u : sentinel;
                 c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
             }
+            if (K == 1) {
 #pragma unroll
-            for (int u = 0; u < kGroup; ++u) offer<T, K>(dist2(q, c[u]), (int)c[u].idx, bd, bi, tie);
+                for (int u = 0; u < kGroup; ++u) offer<T, K>(dist2(q, c[u]), (int)c[u].idx, bd, bi, tie);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kGroup; ++u) {
+                    const T d = dist2(q, c[u]);
+                    tie = tie || (d == bd[K - 1]);            // as offer() would flag it (the k-th best may be stale: conservative)
+                    if (d < bd[K - 1]) { s_bd[cnt][tid] = d; s_bi[cnt][tid] = (int)c[u].idx; ++cnt; }
+                }
+                if (__any(cnt > kBuf - kGroup)) flush();
+            }
         }
     }
+    if (K > 1) flush();
 
     finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
 }
@@ -778,6 +808,19 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict
     const size_t src = (size_t)pos_of[i] * (size_t)k + j;
     if (out_d) out_d[t] = res_d[src];
     if (out_i) out_i[t] = res_i[src];
+}
+
+// Same for the rows of a list of query slots only (after the tie-order resolver rewrote a handful of rows).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_unpermute_rows(const int* __restrict__ slots, int n_slots, const Pt4<T>* __restrict__ qsorted,
+                                                           const T* __restrict__ res_d, const long long* __restrict__ res_i,
+                                                           T* __restrict__ out_d, long long* __restrict__ out_i, int k) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)n_slots * k) return;
+    const int s = slots[t / k]; const int j = (int)(t % k);
+    const size_t src = (size_t)s * (size_t)k + j, dst = (size_t)qsorted[s].idx * (size_t)k + j;
+    if (out_d) out_d[dst] = res_d[src];
+    if (out_i) out_i[dst] = res_i[src];
 }
 
 }  // namespace pcu
