@@ -718,15 +718,33 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         T bd[K]; int bi[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
-        for (int r = lane; r < nrows; r += 64) {
-            const int cz = z0 + r / ny, cy = y0 + r % ny;
-            const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
-            const unsigned s = a.cell_start[lo], e = a.cell_start[lo + (x1 - x0 + 1)];
-            // small K: four candidates per trip, their loads issued together (the pass is latency-bound: a lane's
-            // row is a chain of dependent-free but serially awaited loads otherwise); slots past the row's end are
-            // killed (+inf / NaN d2 never enters the list)
+        // one candidate into this lane's K best under the total order (d2, dataset row)
+        auto take = [&](const T d, const int id) {
+            if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
+#pragma unroll
+                for (int i = K - 1; i > 0; --i) {
+                    const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
+                    const bool gi = lex_less(d, id, bd[i], bi[i]);
+                    bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+                    bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+                }
+                if (K == 1 || lex_less(d, id, bd[0], bi[0])) { bd[0] = d; bi[0] = id; }
+            }
+        };
+        constexpr unsigned kHeavyRow = 256;        // a row with more candidates than this is scanned by the whole wave
+        for (int r0 = 0; r0 < nrows; r0 += 64) {
+            const int r = r0 + lane;
+            unsigned s = 0, e = 0;
+            if (r < nrows) {
+                const int cz = z0 + r / ny, cy = y0 + r % ny;
+                const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
+                s = a.cell_start[lo]; e = a.cell_start[lo + (x1 - x0 + 1)];
+            }
+            const bool heavy = e - s > kHeavyRow;
+            // light rows: one lane per row. Small K: four candidates per trip, their loads issued together (the pass is
+            // latency-bound); slots past the row's end are killed (+inf / NaN d2 never enters the list)
             constexpr int kU = K <= 8 ? 4 : 1;
-            for (unsigned p = s; p < e; p += kU) {
+            for (unsigned p = s; p < (heavy ? s : e); p += kU) {
                 Pt4<T> cc[kU];
 #pragma unroll
                 for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, e - 1u)];
@@ -734,18 +752,20 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 for (int u = 0; u < kU; ++u) {
                     const Pt4<T>& c = cc[u];
                     const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                    const T d = kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= e);
-                    const int id = (int)c.idx;
-                    if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
-#pragma unroll
-                        for (int i = K - 1; i > 0; --i) {
-                            const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
-                            const bool gi = lex_less(d, id, bd[i], bi[i]);
-                            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
-                            bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
-                        }
-                        if (K == 1 || lex_less(d, id, bd[0], bi[0])) { bd[0] = d; bi[0] = id; }
-                    }
+                    take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= e), (int)c.idx);
+                }
+            }
+            // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
+            // lane keeps the best of its share, the rounds below merge the lanes' lists as for light rows
+            unsigned long long hm = __ballot(heavy);
+            while (hm) {
+                const int owner = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                const unsigned hs = (unsigned)__shfl((int)s, owner, 64), he = (unsigned)__shfl((int)e, owner, 64);
+                for (unsigned p = hs + (unsigned)lane; p < he; p += 64u) {
+                    const Pt4<T> c = a.ref[p];
+                    const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                    take(((dx * dx) + (dy * dy)) + (dz * dz), (int)c.idx);
                 }
             }
         }
