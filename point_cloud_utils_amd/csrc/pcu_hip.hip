@@ -777,10 +777,11 @@ static_assert(sizeof(ResultBlock) == 256, "ResultBlock layout");
 
 // Row-order restore of a job's cell-ordered results (either destination may be null).
 template <typename T>
-static int unpermute_enqueue(hipStream_t s, const SearchJob<T>& j, T* dst_d, long long* dst_i) {
+static int unpermute_enqueue(hipStream_t s, const SearchJob<T>& j, T* dst_d, long long* dst_i,
+                             const ResultBlock* rb = nullptr, int* host_block = nullptr, unsigned seq = 0) {
     const long long n_elems = (long long)j.qidx.n * j.k;
     hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((n_elems + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       j.qidx.pos_of, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k);
+                       j.qidx.pos_of, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k, reinterpret_cast<const int*>(rb), host_block, seq);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -878,10 +879,10 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
-        if ((rc = unpermute_enqueue(s, job, dd, di))) break;          // optimistic: redone below if stragglers / ties remain
+        if ((rc = unpermute_enqueue(s, job, dd, di, rb, c->h_pinned, ++c->seq))) break;   // optimistic: redone below if stragglers / ties remain
         tm.mark(2);
-        HIP_TRY(hipMemcpyAsync(c->h_pinned, rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
+        if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
         if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
         if (rc == 1) { if ((rc = unpermute_enqueue(s, job, dd, di))) break; tm.mark(2); }
         else if (rc == 2) {       // the resolver rewrote only the tied queries' rows: restore just those

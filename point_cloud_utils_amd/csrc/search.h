@@ -821,7 +821,15 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict__ pos_of, const T* __restrict__ res_d,
                                                       const long long* __restrict__ res_i, T* __restrict__ out_d,
-                                                      long long* __restrict__ out_i, long long n_elems, int k) {
+                                                      long long* __restrict__ out_i, long long n_elems, int k,
+                                                      const int* __restrict__ result_block, int* host_block, unsigned seq) {
+    // (block 0's first wave also hands the call's result block -- the search counters, final by now -- to pinned host
+    // memory, sequence word last: see k_pnorm_pair)
+    if (host_block && blockIdx.x == 0 && threadIdx.x < 64) {
+        if (threadIdx.x < 63) host_block[threadIdx.x] = result_block[threadIdx.x];
+        __threadfence_system();
+        if (threadIdx.x == 63) __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_elems) return;
     const long long i = t / k; const int j = (int)(t - i * k);
