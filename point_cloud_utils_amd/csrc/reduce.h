@@ -3,7 +3,8 @@
 //   Hausdorff  (src/point_cloud_distance.cpp:221-225): arg-max of the per-source distance array with Eigen's
 //              maxCoeff rule -- strict '>' while visiting rows in order, i.e. the FIRST row attaining the maximum.
 //   Chamfer    (point_cloud_utils/__init__.py:112-115): mean over queries of || nn(q) - q ||_p.
-// Both are deterministic two-stage reductions (per-block partials, then one block), fp64 accumulation for sums.
+// Both are two-stage reductions inside ONE launch (per-block partials; the block that finishes last folds them), fp64
+// accumulation for sums.
 #pragma once
 #include "pcu_types.h"
 #include "grid.h"
@@ -16,48 +17,6 @@ constexpr int kRedBlocksFused = 128;     // per direction in the single-launch e
 template <typename T>
 __device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long long i2) {
     if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
-}
-
-// d[pos]: nearest-neighbour distance of the source point qsorted[pos] (cell order; already sqrt'ed unless squared was
-// requested). The key packs (original row << 32 | pos): ordering by key is ordering by original row, which is the
-// arg-max tie rule; pos is carried along to fetch the neighbour index afterwards.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_argmax_partial(const T* __restrict__ d, const Pt4<T>* __restrict__ qsorted, int n, T* pv, long long* pi) {
-    T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        argmax_combine(v, idx, d[i], ((long long)qsorted[i].idx << 32) | (long long)i);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
-        argmax_combine(v, idx, v2, i2);
-    }
-    __shared__ T sv[kBlock / 64]; __shared__ long long si[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);
-        pv[blockIdx.x] = v; pi[blockIdx.x] = idx;
-    }
-}
-
-// out_v = max value; out_ij = {source row i, its nearest target row j}
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_argmax_final(const T* __restrict__ pv, const long long* __restrict__ pi, int nb,
-                                                         const long long* __restrict__ corr, T* out_v, long long* out_ij) {
-    T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
-    for (int i = threadIdx.x; i < nb; i += kBlock) argmax_combine(v, idx, pv[i], pi[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        T v2 = __shfl_xor(v, o, 64); long long i2 = __shfl_xor(idx, o, 64);
-        argmax_combine(v, idx, v2, i2);
-    }
-    __shared__ T sv[kBlock / 64]; __shared__ long long si[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = idx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, idx, sv[w], si[w]);
-        *out_v = v; out_ij[0] = idx >> 32; out_ij[1] = corr[idx & 0xffffffffll];
-    }
 }
 
 // Hausdorff epilogue in one launch (both directions; nb = 0 for an absent second direction): per-block arg-max
@@ -133,36 +92,10 @@ __device__ __forceinline__ double block_sum(double s) {
 // p-norm codes (numpy.linalg.norm vector ord): 2, 1, +inf, -inf, 0, other
 enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
 
-// partial[b] = sum over the block's queries of || tgt[corr[pos]] - qsorted[pos] ||_p  (fp64 accumulation; queries
-// in cell order). For p == 2 the already computed (non-squared) nn distances d[pos] are summed instead: they are
-// the same numbers, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) (numpy's norm(ord=2, axis=-1) squares, add-reduces in axis
-// order and takes sqrt, in the input dtype).
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pnorm_partial(const Pt4<T>* __restrict__ qsorted, const T* __restrict__ tgt,
-                                                          const long long* __restrict__ corr, const T* __restrict__ d,
-                                                          int n, int pcode, double p, double* partial) {
-    double s = 0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        T v;
-        if (pcode == P_TWO) {
-            v = d[i];
-        } else {
-            const long long c = corr[i];
-            const Pt4<T> q = qsorted[i];
-            const T a = tgt[3 * c] - q.x, b = tgt[3 * c + 1] - q.y, e = tgt[3 * c + 2] - q.z;
-            const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
-            if (pcode == P_ONE) v = (aa + ab) + ae;
-            else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; }
-            else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; }
-            else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));
-            else v = (T)pow((double)(T)((T)pow((double)aa, p) + (T)pow((double)ab, p)) + (double)(T)pow((double)ae, p), 1.0 / p);
-        }
-        s += (double)v;
-    }
-    double r = block_sum(s);
-    if (threadIdx.x == 0) partial[blockIdx.x] = r;
-}
-
+// Per-query norm || tgt[corr[pos]] - qsorted[pos] ||_p, summed with fp64 accumulation (queries in cell order). For p == 2 the
+// already computed (non-squared) nn distances d[pos] are summed instead: they are the same numbers,
+// sqrt(((dx*dx)+(dy*dy))+(dz*dz)) (numpy's norm(ord=2, axis=-1) squares, add-reduces in axis order and takes sqrt, in the
+// input dtype).
 // Chamfer epilogue in one launch: blocks [0, nb0) reduce direction 0, blocks [nb0, nb0 + nb1) direction 1; the block
 // that finishes last (ticket) folds both directions' partials and copies the call's 256-byte result block (counters of
 // both searches + these sums) into pinned host memory, so the call needs no separate final-sum launches and no
@@ -222,13 +155,6 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
         __threadfence_system();
         if (threadIdx.x == 63) { __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sum_final(const double* __restrict__ partial, int nb, double* out) {
-    double s = 0;
-    for (int i = threadIdx.x; i < nb; i += kBlock) s += partial[i];
-    double r = block_sum(s);
-    if (threadIdx.x == 0) *out = r;
 }
 
 }  // namespace pcu

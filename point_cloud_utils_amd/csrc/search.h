@@ -354,8 +354,6 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 //     cuts are those decided after the centre row.
 // Only for open indexes (closed sub-box levels have no sentinel behind their last record).
 template <typename T> struct K1Group { static constexpr int n = 4; };     // records per group (8 measured slower: more bytes gathered past the row ends)
-__device__ __forceinline__ float min2(float a, float b) { return __builtin_fminf(a, b); }
-__device__ __forceinline__ double min2(double a, double b) { return __builtin_fmin(a, b); }
 struct __attribute__((packed, aligned(4))) CellStart4 { unsigned v[4]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dist2_k1(const Pt4<float>& q, const Pt4<float>& c) {
