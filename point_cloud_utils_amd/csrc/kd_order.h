@@ -33,7 +33,8 @@ struct KdNode {
     int left, right;                     // element range [left, right)
     int child1, child2;                  // node ids; -1 = leaf
     int divfeat;
-    int active;                          // (unused)
+    int active;                          // 1 = stub: a node outside every region of interest; it only gets its tight min/max (its
+                                         // parent's divlow/divhigh need it) and is never split (see KdBuild::roi)
     T cutval;
     T bb_lo[3], bb_hi[3];                // the bbox handed DOWN to divideTree (input to middleSplit_)
     typename EncT<T>::type mm_lo[3], mm_hi[3];   // tight min/max of the node's points (encoded, atomics); = computeMinMax
@@ -61,13 +62,47 @@ struct KdBuild {
     int leaf_max;
     int sub_max;                         // nodes with <= sub_max elements go to sub_nodes
     long long* prof;                     // nullable: per-stage cycle counters of sub-tree block 0 (diagnostics)
+    // Regions of interest (few tied queries): balls {x, y, z, R^2} around the tied queries, R = 3 x their k-th distance, i.e.
+    // every tied candidate lies well inside. A child whose handed-down bbox misses all balls becomes a stub. The traversal
+    // treats a stub as one big leaf: distances and the result *set* stay exact, only the order among exactly tied points
+    // INSIDE a stub would be undefined -- and there are none, the tied points are inside the balls. *n_roi == 0: build all.
+    const T* roi; const int* n_roi;
 };
+
+template <typename T>
+__device__ __forceinline__ bool kd_in_roi(const KdBuild<T>& b, const T* lo, const T* hi) {
+    const int n = *b.n_roi;
+    if (n == 0) return true;
+    for (int r = 0; r < n; ++r) {
+        const T* q = b.roi + 4 * r;
+        T d2 = 0;
+        for (int j = 0; j < 3; ++j) { const T a = lo[j] - q[j], c = q[j] - hi[j]; const T m = a > c ? a : c; if (m > 0) d2 += m * m; }
+        if (!(d2 > q[3])) return true;          // (NaN-safe: undecidable counts as inside)
+    }
+    return false;
+}
 
 // Coordinate d of element p, read straight from memory at a computed offset. (A `d == 0 ? x : d == 1 ? y : z`
 // select chain on the wave-uniform d was miscompiled by hipcc 7.2 for gfx950 -- the z arm dereferenced an
 // unset address register -- so no select chain here.)
 template <typename T>
 __device__ __forceinline__ T kd_coord(const Pt4<T>* E, int p, int d) { return reinterpret_cast<const T*>(E + p)[d]; }
+
+// Regions of interest from the list of tied queries (cell-ordered result rows give the k-th distance).
+constexpr int kKdMaxRoi = 64;
+template <typename T>
+__global__ void k_kd_roi(const Pt4<T>* __restrict__ qsorted, const int* __restrict__ qlist, int n_tied, const T* __restrict__ res_d, int k, int squared,
+                         T* __restrict__ roi, int* n_roi) {
+    const int t = threadIdx.x;
+    if (t == 0) *n_roi = n_tied;
+    if (t >= n_tied) return;
+    const int qpos = qlist[t];
+    const Pt4<T> q = qsorted[qpos];
+    const T dk = res_d[(size_t)qpos * k + (k - 1)];
+    T r2 = squared ? dk : dk * dk;
+    r2 = dk < 0 ? (T)INFINITY : r2 * (T)9 * ((T)1 + (T)1e-3);            // R = 3 x the k-th distance (fewer than k found: everything)
+    roi[4 * t] = q.x; roi[4 * t + 1] = q.y; roi[4 * t + 2] = q.z; roi[4 * t + 3] = r2;
+}
 
 // ---- element array + root node ----------------------------------------------------------------------------
 template <typename T>
@@ -167,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b) {
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
+    if (nd.active) return;                 // stub: min/max only
     T mn[3], mx[3];
     for (int j = 0; j < 3; ++j) { mn[j] = dec(nd.mm_lo[j]); mx[j] = dec(nd.mm_hi[j]); }
     int f; T cut;
@@ -198,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     const int wi = blockIdx.x;
-    if (ph == 1 && nd.lt == nd.le) { if (threadIdx.x == 0) { b.chunk_bl[wi] = 0; b.chunk_br[wi] = 0; } return; }
+    if (nd.active || (ph == 1 && nd.lt == nd.le)) { if (threadIdx.x == 0) { b.chunk_bl[wi] = 0; b.chunk_br[wi] = 0; } return; }
     const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     unsigned nl = 0, nr = 0;
     for (int p = s + threadIdx.x; p < e; p += kBlock) {
@@ -218,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
+    if (nd.active) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[ph] = 0; return; }
     if (ph == 1 && nd.lt == nd.le) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[1] = 0; return; }
     const int wi = blockIdx.x, wi0 = wi - chunk, nc = (nd.right - nd.left + kKdChunk - 1) / kKdChunk;
     unsigned before_l = 0, after_r = 0, all_l = 0;
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int ph) {
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
+    if (nd.active) return;
     const int j0 = chunk * kKdChunk, nb = nd.nbad[ph];
     for (int j = j0 + threadIdx.x; j < min(j0 + kKdChunk, nb); j += kBlock) {
         const int pl = b.BLpos[nd.left + j], pr = b.BRpos[nd.left + j];
@@ -278,6 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
         const int i = base + threadIdx.x;
         if (i < n_level) {
             KdNode<T>& nd = b.nodes[b.level_nodes[i]];
+            if (nd.active) continue;            // stub: its min/max is all that was wanted
             const int count = nd.right - nd.left, lim1 = nd.lt, lim2 = nd.le;
             int index;
             if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
@@ -294,7 +333,11 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
             atomicMax(b.max_depth, nd.depth + 1);
             for (int k = 0; k < 2; ++k) {
                 const int id2 = c + k; const int cnt = k ? count - index : index;
-                if (cnt <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = id2;     // finished in LDS later
+                KdNode<T>& ch = k ? r : l;
+                if (cnt > b.leaf_max && !kd_in_roi(b, ch.bb_lo, ch.bb_hi)) {            // outside every region of interest: stub
+                    ch.active = 1;
+                    b.next_nodes[atomicAdd(&s_next, 1)] = id2;                            // one more level, for its min/max only
+                } else if (cnt <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = id2;   // finished in LDS later
                 else b.next_nodes[atomicAdd(&s_next, 1)] = id2;
             }
         }
@@ -669,7 +712,8 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
         const KdNode<T>& nd = a.nodes[f.node];
         bool pop = false;
         if (f.stage == 0) {
-            if (nd.child1 < 0) {                                        // leaf (:1552-1572)
+            if (nd.child1 < 0) {                                        // leaf (:1552-1572) -- or a stub, scanned like one
+                if (nd.active && nd.right - nd.left > 4096) { if (lane == 0) *a.error_flag = 2; return; }   // big unbuilt part: ask for the whole tree
                 const T worst_dist = rd[k - 1];                         // sampled once per leaf
                 for (int base = nd.left; base < nd.right; base += 64) {
                     const int cnt = min(64, nd.right - base);

@@ -541,30 +541,33 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
 // traversal (kd_order.h). Only called when the grid search reported genuine ties.
 template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
-                           KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out) {
+                           KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0) {
     b.leaf_max = leaf_max;
     b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
     // level lists only ever hold nodes with more than sub_max elements
     const size_t max_level = (size_t)M / (size_t)(b.sub_max + 1) + 4;
     // node ids: < 2*max_level for the top levels, plus 2n reserved by each LDS sub-tree block (sum of n <= M)
     const size_t max_nodes = 2 * (size_t)M + 4 * max_level + 16;
-    const size_t max_items = (size_t)M / kKdChunk + max_level + 2;
+    const size_t max_items = (size_t)M / kKdChunk + 3 * max_level + 2;      // (+ stubs: up to two per level node, one chunk each or more)
     const size_t n_sub_cap = 2 * max_level + (size_t)M / (size_t)(b.sub_max / 2 + 1) + 16;
     int* counters = nullptr;
     (void)ar;
     {
         auto al = [](size_t v) { return align_up(v, 256); };
-        const size_t need = al((size_t)M * sizeof(Pt4<T>)) + al(max_nodes * sizeof(KdNode<T>)) + al(64) + 2 * al(max_level * 4) +
-                            2 * al((max_level + 1) * 4) + 2 * al(max_items * 4) + 2 * al((size_t)M * 4) + al(n_sub_cap * 4) + al(16 * 8) + 4096;
+        const size_t need = al((size_t)M * sizeof(Pt4<T>)) + al(max_nodes * sizeof(KdNode<T>)) + al(64) + 2 * al(3 * max_level * 4) +
+                            2 * al((3 * max_level + 1) * 4) + 2 * al(max_items * 4) + 2 * al((size_t)M * 4) + al(n_sub_cap * 4) + al(16 * 8) + 8192;
         if (kd_ws_reserve(c, need)) return -1;
     }
     KdArena ka{c};
     if (ka.get(&b.E, (size_t)M) || ka.get(&b.nodes, max_nodes) || ka.get(&counters, 16)) return -1;
-    if (ka.get(&b.level_nodes, max_level) || ka.get(&b.next_nodes, max_level)) return -1;
-    if (ka.get(&b.level_cbase, max_level + 1) || ka.get(&b.next_cbase, max_level + 1)) return -1;
+    if (ka.get(&b.level_nodes, 3 * max_level) || ka.get(&b.next_nodes, 3 * max_level)) return -1;
+    if (ka.get(&b.level_cbase, 3 * max_level + 1) || ka.get(&b.next_cbase, 3 * max_level + 1)) return -1;
     if (ka.get(&b.chunk_bl, max_items) || ka.get(&b.chunk_br, max_items)) return -1;
     if (ka.get(&b.BLpos, (size_t)M) || ka.get(&b.BRpos, (size_t)M)) return -1;
     if (ka.get(&b.sub_nodes, n_sub_cap)) return -1;
+    T* roi = nullptr; int* n_roi = nullptr;
+    if (ka.get(&roi, 4 * kKdMaxRoi) || ka.get(&n_roi, 16)) return -1;
+    b.roi = roi; b.n_roi = n_roi;
     b.n_nodes = counters; b.n_items = counters + 2;
     *err_out = counters + 3;
     b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
@@ -572,6 +575,12 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     b.prof = nullptr;
     if (getenv("PCU_HIP_PROF_KD")) { if (ka.get(&b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
+    // few tied queries: build only the part of the tree their traversals can touch (kd_order.h, KdBuild::roi)
+    static const bool no_roi = getenv("PCU_HIP_KD_FULL") != nullptr;
+    if (roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && !no_roi)
+        hipLaunchKernelGGL(k_kd_roi<T>, dim3(1), dim3(kKdMaxRoi), 0, s, roi_job->qidx.sorted, roi_job->sc.tt, n_tied, roi_job->out_d, roi_job->k,
+                           roi_job->squared ? 1 : 0, roi, n_roi);
+    else HIP_TRY(hipMemsetAsync(n_roi, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
     const int items_ub = (int)max_items;
@@ -650,26 +659,31 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
 
 template <typename T>
 static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, int n_tt, pcu_hip_stats* st) {
-    KdBuild<T> b; int* err = nullptr; int levels = 0;
     hipEvent_t e0 = c->ev[4], e1 = c->ev[5];
     const bool timed = st && c->time_phases;
     if (timed) (void)hipEventRecord(e0, s);
-    if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr)) return -1;
-    KdSearchArgs<T> a;
-    a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
-    a.k = j.k; a.squared = j.squared ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
-    KdFrame<T>* frames = nullptr;
-    a.stack_cap = levels + 2;
-    if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
-    a.stack = frames;
-    hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
-    HIP_TRY(hipGetLastError());
-    if (timed) (void)hipEventRecord(e1, s);
-    int herr = 0;
-    HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
-    if (timed) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
+    // attempt 0: tree restricted to the tied queries' regions of interest (few ties); attempt 1: the whole tree, if a
+    // traversal wanted to walk into a big unbuilt part (rare; results are exact either way, this is about time)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        KdBuild<T> b; int* err = nullptr; int levels = 0;
+        if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr, attempt == 0 ? &j : nullptr, n_tt)) return -1;
+        KdSearchArgs<T> a;
+        a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
+        a.k = j.k; a.squared = j.squared ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
+        KdFrame<T>* frames = nullptr;
+        a.stack_cap = levels + 2;
+        if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
+        a.stack = frames;
+        hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        int herr = 0;
+        HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (herr == 2 && attempt == 0) continue;
+        if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
+        break;
+    }
+    if (timed) { (void)hipEventRecord(e1, s); HIP_TRY(hipStreamSynchronize(s)); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
     return 0;
 }
 
