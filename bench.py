@@ -158,7 +158,7 @@ def main():
                                    "note": "3 extra steps outside the timed region, phase events on"},
             "chamfer": float(results[0]),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(x_h, y_h)
         print(json.dumps(out), flush=True)
     if distributed:
