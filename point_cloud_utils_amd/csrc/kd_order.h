@@ -92,13 +92,13 @@ __device__ __forceinline__ T kd_coord(const Pt4<T>* E, int p, int d) { return re
 constexpr int kKdMaxRoi = 64;
 template <typename T>
 __global__ void k_kd_roi(const Pt4<T>* __restrict__ qsorted, const int* __restrict__ qlist, int n_tied, const T* __restrict__ res_d, int k, int squared,
-                         T* __restrict__ roi, int* n_roi) {
+                         int row_out, T* __restrict__ roi, int* n_roi) {
     const int t = threadIdx.x;
     if (t == 0) *n_roi = n_tied;
     if (t >= n_tied) return;
     const int qpos = qlist[t];
     const Pt4<T> q = qsorted[qpos];
-    const T dk = res_d[(size_t)qpos * k + (k - 1)];
+    const T dk = res_d[(size_t)(row_out ? (int)q.idx : qpos) * k + (k - 1)];
     T r2 = squared ? dk : dk * dk;
     r2 = dk < 0 ? (T)INFINITY : r2 * (T)9 * ((T)1 + (T)1e-3);            // R = 3 x the k-th distance (fewer than k found: everything)
     roi[4 * t] = q.x; roi[4 * t + 1] = q.y; roi[4 * t + 2] = q.z; roi[4 * t + 3] = r2;
@@ -665,7 +665,7 @@ template <typename T>
 struct KdSearchArgs {
     const Pt4<T>* E; const KdNode<T>* nodes;
     const Pt4<T>* qsorted; const int* qlist; const int* qcount_dev;
-    int k, squared;
+    int k, squared, row_out;
     T* out_d; long long* out_i;
     void* stack; int stack_cap;         // per work item: stack_cap frames (tree depth + 2) in global memory
     int* error_flag;
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
         }
     }
     __syncthreads();
-    const size_t o = (size_t)a.qlist[t] * (size_t)k;                    // cell-ordered result rows
+    const size_t o = (size_t)(a.row_out ? (int)q.idx : a.qlist[t]) * (size_t)k;     // cell-ordered result rows unless row_out
     for (int j = lane; j < k; j += 64) {                                // src/point_cloud_distance.cpp:82-93
         if (j < count) { a.out_i[o + j] = ri[j]; a.out_d[o + j] = a.squared ? rd[j] : sqrt(rd[j]); }
         else { a.out_i[o + j] = -1; a.out_d[o + j] = (T)-1; }

@@ -50,6 +50,8 @@ struct SearchArgs {
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then builds a quantile grid
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
+    int row_out;                    // 1: result row of a query goes to its ORIGINAL row (k >= 4: rows are >= 48 B, scattering whole
+                                    // rows costs less than a row-order restore pass); 0: to its slot in the queries' cell order
     T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
     long long* out_i;               // (nq_total, kreq)  (k_unpermute restores the caller's row order when needed)
     int* unresolved; int* n_unresolved;
@@ -204,7 +206,7 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
     const bool certified = valid && kth < lb;
 
     if (certified) {
-        const size_t o = (size_t)qpos * (size_t)kreq;       // results stay in cell order (coalesced rows); see k_unpermute
+        const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)kreq;       // cell order (coalesced rows; see k_unpermute) unless row_out
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             if (i < kreq) {
@@ -793,13 +795,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         const bool certified = kth < lb;
         if (certified) {
             if (lane < kreq) {
-                const size_t o = (size_t)qpos * (size_t)kreq + lane;
+                const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)kreq + lane;
                 const bool found = my_i != 0x7fffffff;
                 a.out_i[o] = found ? (long long)my_i : -1ll;
                 a.out_d[o] = found ? (a.squared ? my_d : sqrt(my_d)) : (T)-1;
             }
             if (K > 64 && lane + 64 < kreq) {
-                const size_t o = (size_t)qpos * (size_t)kreq + lane + 64;
+                const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)kreq + lane + 64;
                 const bool found = my_i2 != 0x7fffffff;
                 a.out_i[o] = found ? (long long)my_i2 : -1ll;
                 a.out_d[o] = found ? (a.squared ? my_d2 : sqrt(my_d2)) : (T)-1;
@@ -834,6 +836,13 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict
     const size_t src = (size_t)pos_of[i] * (size_t)k + j;
     if (out_d) out_d[t] = res_d[src];
     if (out_i) out_i[t] = res_i[src];
+}
+
+// The call's result block to pinned host memory (sequence word last), for call shapes without an unpermute launch.
+__global__ void k_result_block_to_host(const int* __restrict__ result_block, int* host_block, unsigned seq) {
+    if (threadIdx.x < 63) host_block[threadIdx.x] = result_block[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 63) __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Same for the rows of a list of query slots only (after the tie-order resolver rewrote a handful of rows).
