@@ -67,6 +67,7 @@ struct KdBuild {
     // treats a stub as one big leaf: distances and the result *set* stay exact, only the order among exactly tied points
     // INSIDE a stub would be undefined -- and there are none, the tied points are inside the balls. *n_roi == 0: build all.
     const T* roi; const int* n_roi;
+    int* need_ph2;                       // set when some node has elements equal to its cut value (planeSplit's second loop has work)
 };
 
 template <typename T>
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     const int wi = blockIdx.x;
+    if (ph == 0 && chunk == 0 && threadIdx.x == 0 && !nd.active && nd.lt != nd.le) *b.need_ph2 = 1;
     if (nd.active || (ph == 1 && nd.lt == nd.le)) { if (threadIdx.x == 0) { b.chunk_bl[wi] = 0; b.chunk_br[wi] = 0; } return; }
     const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     unsigned nl = 0, nr = 0;

@@ -57,7 +57,8 @@ struct pcu_hip_ctx {
     // tie-order resolver: its own grow-only workspace (stable addresses across calls, so the captured
     // level-pair graph below stays valid) and one cached executable graph per scalar type
     char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
-    struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[2];
+    struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[4];   // [type][with second planeSplit loop]
+    bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -572,9 +573,15 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     b.n_nodes = counters; b.n_items = counters + 2;
     *err_out = counters + 3;
     b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
-    b.n_cur = counters + 7; b.n_next = counters + 8;
+    b.n_cur = counters + 7; b.n_next = counters + 8; b.need_ph2 = counters + 9;
     b.prof = nullptr;
     if (getenv("PCU_HIP_PROF_KD")) { if (ka.get(&b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
+    // planeSplit's second loop (elements EQUAL to the cut value) has no work on generic data, and its three launches per
+    // level are pure launch floor: the level graph is first replayed without them; if some node turns out to hold such
+    // elements (device flag), the build is redone with them and the context remembers (duplicated points, lattices).
+    int hcnt[16] = {0};
+    for (int rebuild = 0; rebuild < 2; ++rebuild) {
+    const bool with_ph2 = c->kd_need_ph2;
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     // few tied queries: build only the part of the tree their traversals can touch (kd_order.h, KdBuild::roi)
     static const bool no_roi = getenv("PCU_HIP_KD_FULL") != nullptr;
@@ -590,11 +597,11 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // lists has period 2) are captured ONCE into a hipGraph and replayed: the expected log2(M / sub_max) + 2
     // levels first, then two at a time until the device reports an empty level. Replay removes most of the
     // per-launch host cost, which dominated this launch-bound phase.
-    auto enqueue_level_pair = [&](KdBuild<T> bb) {
+    auto enqueue_level_pair = [&](KdBuild<T> bb, bool with_ph2) {
         for (int half = 0; half < 2; ++half) {
             hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
             hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
-            for (int ph = 0; ph < 2; ++ph) {
+            for (int ph = 0; ph < (with_ph2 ? 2 : 1); ++ph) {
                 hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
                 hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
                 hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
@@ -607,15 +614,14 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     };
     int expected = 2;
     for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
-    int hcnt[16];
     if (M > b.sub_max) {
-        auto& G = c->kd_graph[sizeof(T) == 4 ? 0 : 1];
+        auto& G = c->kd_graph[(sizeof(T) == 4 ? 0 : 2) + (with_ph2 ? 1 : 0)];
         const bool use_graph = getenv("PCU_HIP_NO_GRAPH") == nullptr;
         if (use_graph && (!G.exec || G.key_ptr != (const void*)b.E || G.key_m != M || G.key_leaf != leaf_max)) {
             if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
             if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
             HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            enqueue_level_pair(b);
+            enqueue_level_pair(b, with_ph2);
             HIP_TRY(hipStreamEndCapture(s, &G.graph));
             HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
             G.key_ptr = (const void*)b.E; G.key_m = M; G.key_leaf = leaf_max;
@@ -623,7 +629,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         int pairs = (expected + 1) / 2;
         for (int guard = 0; guard < 100000; ++guard) {
             for (int i = 0; i < pairs; ++i) {
-                if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b);
+                if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
@@ -631,6 +637,9 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             if (hcnt[b.n_cur - counters] == 0) break;      // after an even number of levels the roles are as at the start
             pairs = 1;
         }
+    }
+    if (!with_ph2 && hcnt[9]) { c->kd_need_ph2 = true; continue; }
+    break;
     }
     (void)c;
     // finish every small node inside one workgroup's LDS
