@@ -126,8 +126,11 @@ class _Dev:
             self.tdev = a.device
             # the library call is ordered after work queued on torch's current stream, unless this thread asked for its
             # context's private stream (batched workers; they synchronise with the producer themselves)
-            self.stream = None if _lib.use_private_stream() else torch.cuda.current_stream(a.device).cuda_stream
-            self.flags = _lib.PTRS_ON_DEVICE | _flags()
+            # (torch's default stream is the legacy NULL stream, handle 0: STREAM_GIVEN makes the library launch there too,
+            # so that its kernels are ordered after the producers of the input tensors)
+            private = _lib.use_private_stream()
+            self.stream = None if private else torch.cuda.current_stream(a.device).cuda_stream
+            self.flags = _lib.PTRS_ON_DEVICE | _flags() | (0 if private else _lib.STREAM_GIVEN)
             self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
             self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64
             self.t_dtype = a.dtype

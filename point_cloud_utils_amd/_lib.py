@@ -12,6 +12,7 @@ SQUARED = 2
 NO_TIE_ORDER = 4
 TIME_PHASES = 8
 TIME_KERNELS = 16
+STREAM_GIVEN = 32
 
 ERR_INVALID = -1
 

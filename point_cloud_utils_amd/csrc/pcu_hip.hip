@@ -616,7 +616,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
     if (M > b.sub_max) {
         auto& G = c->kd_graph[(sizeof(T) == 4 ? 0 : 2) + (with_ph2 ? 1 : 0)];
-        const bool use_graph = getenv("PCU_HIP_NO_GRAPH") == nullptr;
+        const bool use_graph = getenv("PCU_HIP_NO_GRAPH") == nullptr && s != nullptr;      // (the legacy NULL stream cannot be captured: eager launches there)
         if (use_graph && (!G.exec || G.key_ptr != (const void*)b.E || G.key_m != M || G.key_leaf != leaf_max)) {
             if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
             if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
@@ -866,7 +866,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     if (validate_sizes(nq, nr, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
     if (k > kMaxK) return fail(PCU_HIP_ERR_INVALID, "k = %d > %d is not supported by the gfx950 path yet", k, kMaxK);
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
-    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = pidx ? pidx->occ : (c->occupancy > 0 ? c->occupancy : default_occupancy(k));
@@ -1054,7 +1054,7 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "source", "targets")) return PCU_HIP_ERR_INVALID;
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
-    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
@@ -1120,7 +1120,7 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
     if (validate_sizes(nx, ny, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
     if (isnan(p_norm)) return fail(PCU_HIP_ERR_INVALID, "p_norm is NaN");
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
-    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
@@ -1191,7 +1191,7 @@ static int index_create_impl(pcu_hip_ctx* c, const T* dataset, int64_t nr, int k
     if (k_hint <= 0) k_hint = 1;
     if (k_hint > kMaxK) k_hint = kMaxK;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     pcu_hip_index* p = new pcu_hip_index();
     p->elem_size = (int)sizeof(T); p->device = c->device; p->n = nr;
     p->occ = c->occupancy > 0 ? c->occupancy : default_occupancy(k_hint);

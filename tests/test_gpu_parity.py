@@ -424,3 +424,21 @@ def test_dataset_index_matches_one_shot_calls(pcu, oracle_kind, dtype):
     with pytest.raises(ValueError, match="match the indexed dataset"):
         index.k_nearest_neighbors(q.astype(np.float64 if dtype == np.float32 else np.float32), 1)
     index.close()
+
+
+def test_torch_inputs_produced_on_the_current_stream(pcu):
+    """Torch inputs whose producer kernels are still queued on torch's current (default) stream: the library launches on
+    that stream, so it sees the finished tensors (a private stream would race with the producers)."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for _ in range(3):
+        a = torch.rand((400000, 3), device="cuda", generator=g)
+        for _ in range(20):                       # a queue of dependent producer kernels
+            a = (a * 1.0000001).clamp(0.0, 1.0)
+        b = torch.rand((300000, 3), device="cuda", generator=g)
+        d, c = pcu.k_nearest_neighbors(a, b, 1)   # enqueued behind the producers, no host sync in between
+        torch.cuda.synchronize()
+        d2, c2 = pcu.k_nearest_neighbors(a.clone(), b.clone(), 1)
+        assert torch.equal(c, c2) and torch.equal(d, d2)
+        bb = b[c]
+        assert torch.allclose(d, (a - bb).norm(dim=1), rtol=1e-4, atol=1e-7)
