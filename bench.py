@@ -88,9 +88,9 @@ def main():
     for _ in range(args.warmup):
         pcu.chamfer_distance(x, y)
     # Roofline input: HIP events around the main search launch (k_search1_flat<float>, both directions), recorded by the
-    # library on its launch stream INSIDE the timed region -- on every 4th step only, because each event is a ~6 us
-    # bubble between kernels (8 events per step cost ~10 % of the step).
-    KEV_EVERY = 4
+    # library on its launch stream INSIDE the timed region -- on every 8th step only, because each event is a ~6 us
+    # bubble between kernels.
+    KEV_EVERY = 8
     k_ms, k_n = 0.0, 0
     sync_all()
     t0 = time.perf_counter()
