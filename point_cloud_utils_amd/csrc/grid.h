@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
 constexpr int kBkThreads = 1024;                    // 16 waves per block: the passes are latency-bound
 constexpr int kBkPts = 4;                           // points per thread of the bucket passes
 constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
-constexpr int kBkMaxBuckets = 4096;
+constexpr int kBkMaxBuckets = 8192;                 // LDS: 32 KB (count) / 64 KB (scatter) of bucket counters per 1024-thread block
 constexpr int kBkMaxCellsPerBucket = 4096;
 constexpr int kSortThreads = PCU_SORT_THREADS;
 constexpr int kSortIters = 8;                       // (16 costs 8 more VGPRs: 3 instead of 4 resident blocks per CU)

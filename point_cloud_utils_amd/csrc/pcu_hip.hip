@@ -159,7 +159,7 @@ static int max_cells_for(int64_t n, double occ) {
     if (c > 64.0 * 1024 * 1024) c = 64.0 * 1024 * 1024;
     return (int)c;
 }
-// Bucketed build: applicable when the cells split into <= 4096 buckets of <= 4096 cells (~2k points each) and the
+// Bucketed build: applicable when the cells split into <= 8192 buckets of <= 4096 cells (~2k points each) and the
 // (block, bucket) reservation table stays small; otherwise (tiny or huge clouds, very coarse grids) the atomic build.
 static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     static const bool off = [] { const char* e = getenv("PCU_HIP_INDEX"); return e && strcmp(e, "atomic") == 0; }();
@@ -172,7 +172,7 @@ static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     if (nb > kBkMaxBuckets) return false;
     if ((double)(1 << sh) * occ > 0.5 * (double)kLargeBucket) return false;
     const int64_t blocks = (n + kBkBlockPts - 1) / kBkBlockPts;
-    if (blocks * (int64_t)nb > 8ll * 1024 * 1024) return false;
+    if (blocks * (int64_t)nb > 32ll * 1024 * 1024) return false;      // (block, bucket) reservation table: at most 128 MB
     *shift = sh; *nb_max = nb;
     return true;
 }
