@@ -104,8 +104,8 @@ def main():
             st = pcu.last_stats()
             k_ms += st["ms_kernel_search"]; k_n += st["n_kernel_search"]
             pcu.set_timing(0)
-    res_t = torch.tensor(results, dtype=torch.float32, device=dev)
     if distributed:   # the only collective of the job: gather the per-pair scalars (K floats per rank)
+        res_t = torch.tensor(results, dtype=torch.float32, device=dev)
         gathered = [torch.empty_like(res_t) for _ in range(world)]
         dist.all_gather(gathered, res_t)
     sync_all()
