@@ -67,3 +67,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libpcu_oracle" not in txt and "libpcu_ref" not in txt, f
+
+
+def test_dataset_index_validates_before_touching_the_gpu():
+    import point_cloud_utils_amd as pcu
+    with pytest.raises(ValueError, match="Invalid scalar type"):
+        pcu.DatasetIndex(np.zeros((5, 3), dtype=np.int32))
+    with pytest.raises(ValueError, match=r"shape \(m, 3\)"):
+        pcu.DatasetIndex(np.zeros((5, 2)))
+    with pytest.raises(ValueError, match=r"shape \(m, 3\)"):
+        pcu.DatasetIndex(np.zeros((0, 3)))
+
+
+def test_timing_switch_is_a_module_level_setting():
+    import point_cloud_utils_amd as pcu
+    old = pcu.set_timing(2)
+    try:
+        assert pcu.set_timing(0) == 2
+        from point_cloud_utils_amd import _lib
+        pcu.set_timing(1)
+        assert pcu._flags() & _lib.TIME_KERNELS and not (pcu._flags() & _lib.TIME_PHASES)
+    finally:
+        pcu.set_timing(old)
