@@ -727,21 +727,46 @@ __global__ __launch_bounds__(kBlock) void k_hist_merge(const unsigned* __restric
     hist[i] = s;
 }
 
-// Per axis (3 threads): zoom the range to the bins that hold all but n/4096 of the mass at either end.
+// Per axis (one wave each: launch 3 blocks of 64): zoom the range to the bins that hold all but n/4096 of the mass at either
+// end. b0 = number of leading bins whose cumulative count (with the underflow bin) stays <= tail, b1 likewise from the top;
+// the cumulative counts are monotone, so both are plain counts over a wave-wide prefix / suffix scan (16 bins per lane).
 template <typename T>
-__global__ void k_quant_zoom(QuantState<T>* qs, const unsigned* __restrict__ hist, int n) {
-    const int a = threadIdx.x;
+__global__ __launch_bounds__(64) void k_quant_zoom(QuantState<T>* qs, const unsigned* __restrict__ hist, int n) {
+    const int a = blockIdx.x, lane = threadIdx.x;
     if (a >= 3) return;
     const unsigned* h = hist + a * (kHistBins + 2);
     const T lo = qs->lo[a], hi = qs->hi[a];
     const double w = ((double)hi - (double)lo) / kHistBins;
     if (!(w > 0)) return;
     const double tail = (double)n / 4096.0;
-    double c = h[0]; int b0 = 0;
-    while (b0 < kHistBins - 1 && c + h[1 + b0] <= tail) { c += h[1 + b0]; ++b0; }
-    c = h[kHistBins + 1]; int b1 = kHistBins - 1;
-    while (b1 > b0 && c + h[1 + b1] <= tail) { c += h[1 + b1]; --b1; }
-    qs->lo[a] = (T)((double)lo + b0 * w); qs->hi[a] = (T)((double)lo + (b1 + 1) * w);
+    constexpr int kPer = kHistBins / 64;                   // 16 bins per lane
+    unsigned v[kPer]; unsigned long long loc = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) { v[i] = h[1 + lane * kPer + i]; loc += v[i]; }
+    // prefix: P[i] = underflow + sum of bins 0..i
+    unsigned long long inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    unsigned long long run = inc - loc + h[0];
+    int c0 = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) { run += v[i]; c0 += ((double)run <= tail) ? 1 : 0; }
+    // suffix: S[i] = overflow + sum of bins i..last
+    unsigned long long dec = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_down(dec, o, 64); if (lane + o < 64) dec += t; }
+    unsigned long long runs = dec - loc + h[kHistBins + 1];
+    int c1 = 0;
+#pragma unroll
+    for (int i = kPer - 1; i >= 0; --i) { runs += v[i]; c1 += ((double)runs <= tail) ? 1 : 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+    if (lane == 0) {
+        const int b0 = c0 < kHistBins - 1 ? c0 : kHistBins - 1;
+        int b1 = kHistBins - 1 - c1;
+        if (b1 < b0) b1 = b0;
+        qs->lo[a] = (T)((double)lo + b0 * w); qs->hi[a] = (T)((double)lo + (b1 + 1) * w);
+    }
 }
 
 // Cubic cells of about `target_cells` over the core range qs (exact bbox kept in gmin/gmax for certification).

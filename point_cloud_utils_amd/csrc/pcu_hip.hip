@@ -305,7 +305,7 @@ static int core_range_enqueue(Arena& ar, const GridIndex<T>& base, const T* d_pt
     for (int r = 0; r < 3; ++r) {
         hipLaunchKernelGGL(k_hist_axis<T>, dim3(kHistBlocks), dim3(kBlock), 0, s, d_pts, base.n, qs, partial);
         hipLaunchKernelGGL(k_hist_merge, dim3((3 * (kHistBins + 2) + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, kHistBlocks, hist);
-        hipLaunchKernelGGL(k_quant_zoom<T>, dim3(1), dim3(64), 0, s, qs, hist, base.n);
+        hipLaunchKernelGGL(k_quant_zoom<T>, dim3(3), dim3(64), 0, s, qs, hist, base.n);
     }
     HIP_TRY(hipGetLastError());
     *out_qs = qs;
