@@ -199,33 +199,46 @@ __global__ __launch_bounds__(kBlock) void k_make_grid(const GridSide<T> a0, cons
     make_grid_body<T>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel);
 }
 
+// Cell id + rank-in-cell of every point. The ranks come from a returning atomicAdd on the cell's counter, and those
+// are memory-side on MI355X: thousands of points of a dense cluster in one cell serialise on one address (a refit build
+// over a tight cluster took ~180 us, a coarse build over a Gaussian blob ~1 ms). Each block therefore first aggregates its
+// 256 points by cell in a small LDS hash table (LDS atomics), issues ONE returning global atomic per distinct cell, and
+// hands out the ranks locally. On spread-out data (every point its own cell) this is the same number of global atomics.
+constexpr int kCountSlots = 512;           // >= 2 x kBlock: open addressing always finds a slot
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp,
                                                   unsigned* __restrict__ cell_of, unsigned* __restrict__ rank,
                                                   unsigned* counts) {
+    __shared__ unsigned s_key[kCountSlots], s_cnt[kCountSlots], s_base[kCountSlots];
+    for (int i = threadIdx.x; i < kCountSlots; i += kBlock) { s_key[i] = 0xffffffffu; s_cnt[i] = 0u; }
+    __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const T x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-    if (gp->closed) {      // sub-box level: points outside the box are simply not part of this index
-        const T tx = (x - gp->org[0]) * gp->inv_h, ty = (y - gp->org[1]) * gp->inv_h, tz = (z - gp->org[2]) * gp->inv_h;
-        const bool in = tx >= 0 && tx < (T)gp->G[0] && ty >= 0 && ty < (T)gp->G[1] && tz >= 0 && tz < (T)gp->G[2];
-        if (!in) { cell_of[i] = 0xffffffffu; rank[i] = 0; return; }
+    unsigned c = 0xffffffffu, slot = 0, lr = 0;
+    if (i < n) {
+        const T x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+        bool in = true;
+        if (gp->closed) {      // sub-box level: points outside the box are simply not part of this index
+            const T tx = (x - gp->org[0]) * gp->inv_h, ty = (y - gp->org[1]) * gp->inv_h, tz = (z - gp->org[2]) * gp->inv_h;
+            in = tx >= 0 && tx < (T)gp->G[0] && ty >= 0 && ty < (T)gp->G[1] && tz >= 0 && tz < (T)gp->G[2];
+        }
+        if (in) {
+            const int cx = grid_cell(*gp, 0, x), cy = grid_cell(*gp, 1, y), cz = grid_cell(*gp, 2, z);
+            c = (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], cy, cz), cx, cx);
+            slot = (c * 2654435761u) >> 23;                      // 9 bits
+            for (;;) {
+                const unsigned prev = atomicCAS(&s_key[slot], 0xffffffffu, c);
+                if (prev == 0xffffffffu || prev == c) break;
+                slot = (slot + 1) & (kCountSlots - 1);
+            }
+            lr = atomicAdd(&s_cnt[slot], 1u);
+        }
+        cell_of[i] = c;
     }
-    const int cx = grid_cell(*gp, 0, x), cy = grid_cell(*gp, 1, y), cz = grid_cell(*gp, 2, z);
-    const unsigned c = (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], cy, cz), cx, cx);
-    cell_of[i] = c;
-    // A wave whose lanes all fall into one cell (degenerate grids: a far outlier inflating the bbox, duplicated
-    // points) issues ONE atomic instead of 64 on the same address.
-    const unsigned long long act = __ballot(1);
-    const int lane = threadIdx.x & 63, first = __ffsll((long long)act) - 1;
-    if (__all(c == (unsigned)__shfl((int)c, first, 64))) {
-        unsigned base = 0;
-        if (lane == first) base = atomicAdd(&counts[c], (unsigned)__popcll(act));
-        base = (unsigned)__shfl((int)base, first, 64);
-        rank[i] = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
-    } else {
-        rank[i] = atomicAdd(&counts[c], 1u);
-    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kCountSlots; k += kBlock)
+        if (s_key[k] != 0xffffffffu) s_base[k] = atomicAdd(&counts[s_key[k]], s_cnt[k]);
+    __syncthreads();
+    if (i < n) rank[i] = c != 0xffffffffu ? s_base[slot] + lr : 0u;
 }
 
 // ---- exclusive scan over `counts[0..m)` in place; counts[m] receives the total -------------------------
