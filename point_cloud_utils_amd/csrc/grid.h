@@ -355,9 +355,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
 // The count/scan/scatter pipeline above spends most of its time in one returning *device-scope* atomic per point (1M
 // atomics = 41 us on MI355X: they are executed memory-side, 39 MB of write traffic for 4 MB of counters). The bucketed
 // build is a two-level MSD counting sort on the linear (snake) cell id that keeps all per-point atomics in LDS:
-//   k_bucket_count    blocks of 4096 points: LDS histogram over *buckets* (runs of 2^shift consecutive cells, ~2k
+//   k_bucket_count    blocks of 8192 points: LDS histogram over *buckets* (runs of 2^shift consecutive cells, ~2k
 //                     points each); one returning global atomic per (block, non-empty bucket) reserves the block's
-//                     slice of the bucket                                    [~120k global atomics instead of 1M]
+//                     slice of the bucket                                     [~60k global atomics instead of 1M]
 //   k_bucket_scatter  same blocks: prefix of the bucket totals, LDS rank inside (block, bucket), records written into
 //                     `tmp` grouped by bucket (runs of ~8 records)
 //   k_bucket_sort     one 512-thread block per bucket: LDS histogram over the bucket's cells, scan -> cell_start; the
@@ -369,8 +369,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
 //                     It exits at once when there is no such bucket.
 // Any valid cell order gives the same search results; the order inside a cell is arbitrary in both builds.
 constexpr int kBkThreads = 1024;                    // 16 waves per block: the passes are latency-bound
-constexpr int kBkPts = 4;                           // points per thread of the bucket passes
-constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 4096 points per block
+#ifndef PCU_BK_PTS
+#define PCU_BK_PTS 8
+#endif
+constexpr int kBkPts = PCU_BK_PTS;                  // points per thread of the bucket passes (tuning knob)
+constexpr int kBkBlockPts = kBkThreads * kBkPts;    // 8192 points per block (4096: +4 % step time, 16384: +2 %)
 constexpr int kBkMaxBuckets = 8192;                 // LDS: 32 KB (count) / 64 KB (scatter) of bucket counters per 1024-thread block
 constexpr int kBkMaxCellsPerBucket = 4096;
 constexpr int kSortThreads = PCU_SORT_THREADS;
