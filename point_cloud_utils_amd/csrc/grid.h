@@ -52,7 +52,10 @@ __device__ __forceinline__ bool take_ticket(unsigned* ticket, unsigned nblocks) 
     return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
 }
 
-constexpr int kBboxBlocks = 256;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz
+#ifndef PCU_BBOX_BLOCKS
+#define PCU_BBOX_BLOCKS 256
+#endif
+constexpr int kBboxBlocks = PCU_BBOX_BLOCKS;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz
 
 // pts: row-major (n,3). Lane i reads 3 consecutive scalars at 3*i: a wave covers one contiguous 768 B
 // (f32) span with three strided dword loads, all of whose sectors are consumed. No atomics: every block

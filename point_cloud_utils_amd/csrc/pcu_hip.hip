@@ -354,7 +354,10 @@ constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 12
 constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
 constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
                                         // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)
-constexpr int kWaveBlocks = 512;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
+#ifndef PCU_WAVE_BLOCKS
+#define PCU_WAVE_BLOCKS 512
+#endif
+constexpr int kWaveBlocks = PCU_WAVE_BLOCKS;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
 static bool use_gather_kernels() { static const bool v = getenv("PCU_HIP_TILE") == nullptr; return v; }
 static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }

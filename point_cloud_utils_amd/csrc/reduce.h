@@ -12,7 +12,10 @@
 namespace pcu {
 
 constexpr int kRedBlocks = 1024;
-constexpr int kRedBlocksFused = 128;     // per direction in the single-launch epilogues: every block takes one same-address ticket
+#ifndef PCU_RED_BLOCKS
+#define PCU_RED_BLOCKS 128
+#endif
+constexpr int kRedBlocksFused = PCU_RED_BLOCKS;     // per direction in the single-launch epilogues: every block takes one same-address ticket
 
 template <typename T>
 __device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long long i2) {
