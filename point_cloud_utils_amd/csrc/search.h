@@ -19,11 +19,10 @@
 // accepted). Uncertified queries are appended to `unresolved` and re-run by the host loop with a larger R or a
 // coarser grid until the scanned box is the whole grid (LB = +inf).
 //
-// Ties: MODE_FAST only *detects* that an exact tie may matter (equal d2 met at the k-th boundary, or equal
-// neighbours in the final list) and appends the query to `ties`; MODE_LEX re-runs those queries with the total
-// order (d2, dataset row) and K >= k+1 slots, and reports which of them have a genuine tie inside the
-// top-(k+1) (`true_ties`), for which the order of the reference is defined by its kd-tree traversal
-// (see tie_order.h).
+// Ties: the lane-per-query passes only *detect* that an exact tie may matter (equal d2 met at the k-th boundary, or equal
+// neighbours in the final list) and append the query to `ties`; the wave-per-query pass re-runs those queries under the
+// total order (d2, dataset row) with K >= k+1 slots and reports which of them have a genuine tie inside the top-(k+1)
+// ("true ties"), for which the order of the reference is defined by its kd-tree traversal (kd_order.h).
 #pragma once
 #include "pcu_types.h"
 #include "grid.h"
@@ -47,7 +46,7 @@ struct SearchArgs {
                                     // pass (via the tie list) instead of scanning them serially: one heavy cell next to a query
                                     // must not turn a wave into a millisecond-long pole
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
-    int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then builds a quantile grid
+    int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then refits the dataset grid (pcu_hip.hip, search_finish)
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
     int row_out;                    // 1: result row of a query goes to its ORIGINAL row (k >= 4: rows are >= 48 B, scattering whole
@@ -55,7 +54,7 @@ struct SearchArgs {
     T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
     long long* out_i;               // (nq_total, kreq)  (k_unpermute restores the caller's row order when needed)
     int* unresolved; int* n_unresolved;
-    int* ties;       int* n_ties;         // MODE_FAST: possible tie; MODE_LEX: genuine tie ("true_ties")
+    int* ties;       int* n_ties;         // lane passes: possible tie; wave pass: genuine tie ("true ties")
 };
 
 // Append `value` for lanes with `flag` set; one atomic per wave.
@@ -487,8 +486,11 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         }
     };
     next_run();
+    // Ping-pong: A is evaluated while B's four loads are in flight, and vice versa. The loads are unconditional
+    // straight-line code (a lane that has just run out of work fetches the +inf sentinel records once): loads issued under
+    // a branch would make the compiler wait for them at the join, i.e. before the older group is evaluated.
     const unsigned sent_off = a.n_ref * kRec;
-    if (live) {     // ping-pong, unconditional loads: see k_search1<T, true>
+    if (live) {
         Pt4<T> a0, a1, a2, a3, b0, b1, b2, b3;
         { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
         for (;;) {
