@@ -9,9 +9,16 @@ ranks with no data-path collective (weak scaling); the per-step scalars are gath
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task description): metric/value = whole-job query-points/s,
-plus `roofline` (dominant kernel k_search<float,1>: algorithmic bytes per launch / HIP-event launch time
-vs the 8 TB/s HBM peak) and `cpu_baseline` (the reference's nanoflann path timed on this box's host cores).
+Prints ONE JSON line on rank 0 (contract in the task description): metric/value = whole-job query-points/s, plus
+  roofline      dominant kernel k_search1_flat<float> (both directions in one launch): SURVEY 8d algorithmic bytes of the
+                Chamfer row (24 B per query-point) / HIP-event launch time vs the 8 TB/s HBM peak; measured HBM traffic and the
+                issue-side counters (VALU / SALU issue fraction, active lanes) come from profiles/hbm_traffic.json, which
+                profiles/postprocess.py derives from the round's rocprofv3 --pmc passes;
+  cpu_baseline  the reference's nanoflann path on this box's host cores (median of 3; search-only seconds beside it);
+  parity        the GPU result of the timed pair against the reference's result on the SAME arrays (value + both index arrays).
+
+Other BASELINE configs (parity-test cases): ``--config c2|c3|c4|c5`` prints the same kind of line for
+k_nearest_neighbors k=1 1M/1M, k=16 4M/4M, batched Hausdorff 256k pairs (32 pairs per GPU), Chamfer bunny-vs-1M f64.
 """
 import argparse
 import json
@@ -32,24 +39,73 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per cloud (default: the headline 1M)")
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--pairs", type=int, default=32, help="c4: pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(x, y):
-    """The reference's CPU path (oracle/_ref = its own nanoflann.hpp; else the C restatement) timed as the
-    reference behaves: input copies + 3x kd-tree build + OpenMP search on all host cores, both directions,
-    plus the numpy tail of chamfer_distance. One full 1M-vs-1M Chamfer is ~5-20 s of CPU work."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_chamfer(x, y, kind, timing=None):
+    """chamfer_distance as the reference computes it (point_cloud_utils/__init__.py:84-120) on the oracle's KNN; returns
+    (value, corrs_x_to_y, corrs_y_to_x) and adds the kd-tree build / search seconds of both KNN calls to `timing`."""
+    import numpy as np
+    import oracle
+    t1, t2 = {}, {}
+    _, cxy = oracle.knn(x, y, 1, kind=kind, timing=t1)
+    _, cyx = oracle.knn(y, x, 1, kind=kind, timing=t2)
+    cxy, cyx = cxy[:, 0], cyx[:, 0]
+    dxy = np.linalg.norm(x[cyx] - y, axis=-1).mean()
+    dyx = np.linalg.norm(y[cxy] - x, axis=-1).mean()
+    if timing is not None:
+        timing["build_s"] = t1.get("build_s", 0.0) + t2.get("build_s", 0.0)
+        timing["search_s"] = t1.get("search_s", 0.0) + t2.get("search_s", 0.0)
+    return dxy + dyx, cxy, cyx
+
+
+def cpu_baseline(x, y, samples=3):
+    """The reference's CPU path (oracle/_ref = its own nanoflann.hpp; else the C restatement) timed as the reference
+    behaves: input copies + 3x kd-tree build + OpenMP search on all host cores, both directions, plus the numpy tail of
+    chamfer_distance. Median of `samples` full 1M-vs-1M Chamfer evaluations (~2-20 s each). Returns (report, last result)."""
+    import numpy as np
     import oracle
     oracle.build()
     kind = "ref" if oracle.have_ref() else "port"
-    t0 = time.perf_counter()
-    oracle.chamfer_distance(x, y, kind=kind)
-    dt = time.perf_counter() - t0
+    ts, searches, res = [], [], None
+    for _ in range(samples):
+        tm = {}
+        t0 = time.perf_counter()
+        res = cpu_chamfer(x, y, kind, tm)
+        ts.append(time.perf_counter() - t0)
+        searches.append(tm.get("search_s", 0.0))
+    dt = float(np.median(ts))
     cores = os.cpu_count() or 1
-    return {"value": (x.shape[0] + y.shape[0]) / dt, "unit": "query-points/s", "cores": cores if kind == "ref" else 1,
-            "kind": "reference" if kind == "ref" else "port",
-            "sample": f"1 full chamfer_distance {x.shape[0]}-vs-{y.shape[0]} fp32 (the GPU step's own pair), {dt:.2f} s"}
+    rep = {"value": (x.shape[0] + y.shape[0]) / dt, "unit": "query-points/s", "cores": cores if kind == "ref" else 1,
+           "kind": "reference" if kind == "ref" else "port", "cpu_model": cpu_model(),
+           "seconds": [round(t, 3) for t in ts], "search_only_seconds": [round(t, 3) for t in searches],
+           "search_only_value": (x.shape[0] + y.shape[0]) / float(np.median(searches)) if min(searches) > 0 else None,
+           "sample": f"median of {samples} full chamfer_distance {x.shape[0]}-vs-{y.shape[0]} fp32 evaluations of the GPU step's own pair "
+                     f"(3x kd-tree build + search per direction, as the reference does; {dt:.2f} s)"}
+    return rep, res
+
+
+def counters():
+    """Issue-side counters and HBM traffic of the dominant kernel, from the round's rocprofv3 --pmc passes (tracked file)."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(tp))
+    except Exception:
+        return {}
 
 
 def main():
@@ -71,18 +127,21 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.config != "headline":
+        return other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync_all)
+
     n = args.points
     # pair p uses seeds 1000+2p / 1001+2p; one pair per rank
     x_h = np.random.default_rng(1000 + 2 * rank).random((n, 3), dtype=np.float32)
     y_h = np.random.default_rng(1001 + 2 * rank).random((n, 3), dtype=np.float32)
     x, y = torch.from_numpy(x_h).to(dev), torch.from_numpy(y_h).to(dev)
     results = [0.0] * max(args.steps, 1)          # per-step scalars stay on the host until the final gather
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     pcu.set_timing(0)
     pcu.chamfer_distance(x, y)        # initialisation, not a step: creates the context, loads the code object, sizes the workspace
@@ -128,19 +187,28 @@ def main():
         steps = max(args.steps, 1)
         qpts_per_step = 2 * n * world
         value = qpts_per_step * steps / dt
-        # dominant kernel: k_search1_flat<float>, ONE launch for both directions = 2n queries, each against the other
-        # cloud's n points. Algorithmic bytes (B_knn with k=1, s=4): 3*4 (query) + 3*4 (its share of the
-        # dataset) + 4+8 (distance, index) = 36 B per query -> 72n B per launch
-        alg_bytes = 36.0 * 2 * n
+        # Dominant kernel: k_search1_flat<float>, ONE launch for both directions = 2n queries, each against the other cloud's n
+        # points. Algorithmic bytes of the Chamfer row (p = 2, no indices): every input read once per role,
+        # 2 * 3 * 4 * (N + M) = 24 B per query-point -> 48 MB per launch at 1M-vs-1M (the fused epilogue writes no rows).
+        alg_bytes = 24.0 * 2 * n
         avg_ms = k_ms / max(k_n, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("k_search1_flat_f32_bytes_per_launch")
-            except Exception:
-                traffic = None
+        cnt = counters()
+        traffic = cnt.get("k_search1_flat_f32_bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": "k_search1_flat<float> (both directions in one launch, fused Chamfer epilogue)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                "alg_bytes_per_launch": alg_bytes, "alg_bytes_rule": "SURVEY 8d Chamfer row: 24 B per query-point",
+                "knn_rows_bytes_per_launch": 36.0 * 2 * n,
+                "knn_rows_note": "B_knn (36 B/query incl. the (d, idx) rows) applies to k_nearest_neighbors / return_index calls, not to this metric",
+                "avg_launch_ms": avg_ms, "launches_timed": k_n,
+                "timing": f"HIP events around the main search launch of every {KEV_EVERY}th timed step",
+                "whole_op": {"alg_bytes_per_step": 48.0 * n * world, "achieved_GBps": 48.0 * n * world / (dt / steps) / 1e9,
+                             "frac": 48.0 * n * world / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
+                             "note": "all launches of the step + host; SURVEY 8d: 2*3*4*(N+M) bytes"}}
+        for k in ("valu_issue_frac", "salu_issue_frac", "active_lane_frac", "valu_insts_per_wave", "salu_insts_per_wave", "counters_source"):
+            if k in cnt:
+                roof[k] = cnt[k]
         out = {
             "metric": "query-points/s, Chamfer 1M-vs-1M fp32", "value": value, "unit": "query-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
@@ -148,19 +216,113 @@ def main():
             "config": {"workload": f"chamfer_distance, {n}-vs-{n} fp32 U[0,1)^3 clouds, one independent pair per GPU per step, "
                                    "inputs resident in HBM, scalar results gathered once (RCCL all_gather)",
                        "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_search1_flat<float> (both directions in one launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
-                         "whole_op": {"alg_bytes_per_step": 48.0 * n * world, "achieved_GBps": 48.0 * n * world / (dt / steps) / 1e9,
-                                      "note": "SURVEY 8d: Chamfer p=2 without indices = 2*3*4*(N+M) bytes; all launches of the step + host"},
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": k_n,
-                         "timing": f"HIP events around the main search launch of every {KEV_EVERY}th timed step"},
+            "roofline": roof,
             "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
                                    "note": "3 extra steps outside the timed region, phase events on"},
             "chamfer": float(results[0]),
         }
+        ref = None
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0, N = 1 only
-            out["cpu_baseline"] = cpu_baseline(x_h, y_h)
+            out["cpu_baseline"], ref = cpu_baseline(x_h, y_h)
+        if not args.no_parity and world == 1:
+            # parity on the arrays that were timed: the reference's value and BOTH index arrays
+            import oracle
+            if ref is None:
+                oracle.build()
+                ref = cpu_chamfer(x_h, y_h, "ref" if oracle.have_ref() else "port")
+            ch0, cxy0, cyx0 = ref
+            _, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)
+            rel = abs(float(results[0]) - float(ch0)) / abs(float(ch0))
+            idx_equal = bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0))
+            same_every_step = bool(all(r == results[0] for r in results[:steps]))
+            out["parity"] = {"chamfer_rel": rel, "tol": 1e-4, "idx_equal": idx_equal, "reference_value": float(ch0),
+                             "identical_over_steps": same_every_step,
+                             "checker": "oracle/_ref (the reference's nanoflann.hpp)" if oracle.have_ref() else "oracle port"}
+            assert rel <= 1e-4, f"Chamfer value differs from the reference: {results[0]} vs {ch0}"
+            assert idx_equal, "Chamfer correspondences differ from the reference"
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync_all):
+    """BASELINE configs 2-5: same timing protocol (device-resident inputs, barrier + sync, max over ranks), parity against
+    the oracle outside the timed region. One JSON line on rank 0."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cloud
+    oracle.build()
+    kind = "ref" if oracle.have_ref() else "port"
+    cfg = args.config
+    parity = {}
+    if cfg in ("c2", "c3"):
+        n, k = (1_000_000, 1) if cfg == "c2" else (4_000_000, 16)
+        q, r = cloud(1000 + 2 * rank, n, np.float32), cloud(1001 + 2 * rank, n, np.float32)
+        tq, tr = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)
+        step = lambda: pcu.k_nearest_neighbors(tq, tr, k)
+        units, s = n, 4
+        alg = 3 * s * n + 3 * s * n + n * k * (s + 8)
+        name = f"k_nearest_neighbors k={k}, {n}-vs-{n} fp32"
+        def check():
+            d, c = pcu.k_nearest_neighbors(tq, tr, k)
+            d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
+            return {"idx_equal": bool(np.array_equal(c.cpu().numpy(), c0)), "dist_bits_equal": bool(np.array_equal(d.cpu().numpy(), d0)), "stats": pcu.last_stats()}
+    elif cfg == "c4":
+        npairs, n = args.pairs, 262144
+        pairs = [(torch.from_numpy(cloud(1000 + 2 * (rank * npairs + p), n, np.float32)).to(dev),
+                  torch.from_numpy(cloud(1001 + 2 * (rank * npairs + p), n, np.float32)).to(dev)) for p in range(npairs)]
+        from point_cloud_utils_amd import batched
+        step = lambda: batched._map_chunks("hausdorff", lambda p: pairs[p], list(range(npairs)), 4)
+        units, alg = npairs * 2 * n, npairs * 2 * 3 * 4 * 2 * n
+        name = f"hausdorff_distance, {npairs} independent {n}-vs-{n} fp32 pairs per GPU (batch entry point)"
+        def check():
+            rows = step()
+            ok = True
+            for p in range(min(2, npairs)):
+                h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
+                ok &= tuple(rows[p]) == tuple(float(v) for v in h0)
+            return {"pairs_checked": min(2, npairs), "tuples_equal": bool(ok)}
+    else:
+        bunny = np.load(os.path.join(ROOT, "tests", "golden", "bunny_v.npy")).astype(np.float64)
+        f = np.load(os.path.join(ROOT, "tests", "golden", "bunny_f.npy"))
+        from conftest import mesh_samples
+        S = mesh_samples(bunny, f, 1_000_000, seed=5)
+        tb, ts_ = torch.from_numpy(bunny).to(dev), torch.from_numpy(S).to(dev)
+        step = lambda: pcu.chamfer_distance(tb, ts_, return_index=True)
+        units, alg = len(bunny) + len(S), 2 * 24 * (len(bunny) + len(S)) + 8 * (len(bunny) + len(S))
+        name = "chamfer_distance(return_index=True), bunny (2,885 vertices) vs 1M mesh samples, fp64"
+        def check():
+            ch, cxy, cyx = step()
+            ch0, cxy0, cyx0 = oracle.chamfer_distance(bunny, S, return_index=True, kind=kind)
+            return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
+                    "chamfer_rel": abs(float(ch) - float(ch0)) / float(ch0), "tol": 1e-6}
+    pcu.set_timing(0)
+    step()
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        if not args.no_parity:
+            parity = check()
+        steps = max(args.steps, 1)
+        out = {"metric": f"query-points/s, {name}", "value": units * world * steps / dt, "unit": "query-points/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64" if cfg == "c5" else "f32", "data": "synthetic",
+               "config": {"workload": name + ", inputs resident in HBM", "baseline_config": cfg},
+               "roofline": {"bound": "hbm", "achieved": alg / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_step": alg,
+                            "note": "whole op (all launches + host) against SURVEY 8d's algorithmic bytes; no per-kernel events in this mode"},
+               "parity": parity}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

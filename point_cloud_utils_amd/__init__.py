@@ -124,13 +124,10 @@ class _Dev:
             self.a, self.b = a.contiguous(), b.contiguous()
             self.device = a.device.index if a.device.index is not None else torch.cuda.current_device()
             self.tdev = a.device
-            # the library call is ordered after work queued on torch's current stream, unless this thread asked for its
-            # context's private stream (batched workers; they synchronise with the producer themselves)
-            # (torch's default stream is the legacy NULL stream, handle 0: STREAM_GIVEN makes the library launch there too,
-            # so that its kernels are ordered after the producers of the input tensors)
-            private = _lib.use_private_stream()
-            self.stream = None if private else torch.cuda.current_stream(a.device).cuda_stream
-            self.flags = _lib.PTRS_ON_DEVICE | _flags() | (0 if private else _lib.STREAM_GIVEN)
+            # the library launches on torch's current stream, so its kernels are ordered after the producers of the input
+            # tensors (torch's default stream is the legacy NULL stream, handle 0: STREAM_GIVEN makes NULL mean exactly that)
+            self.stream = torch.cuda.current_stream(a.device).cuda_stream
+            self.flags = _lib.PTRS_ON_DEVICE | _flags() | _lib.STREAM_GIVEN
             self.pa, self.pb = self.a.data_ptr(), self.b.data_ptr()
             self.np_dtype = np.float32 if a.dtype == torch.float32 else np.float64
             self.t_dtype = a.dtype
@@ -162,6 +159,14 @@ def _record(st):
     _last_stats[0] = st
 
 
+def _squeeze(dists, corrs, n, k):
+    """npe::move(..., squeeze): singleton dimensions are dropped, as numpy.squeeze does -- (n,) for k == 1 (pinned by the
+    reference's tests/test_examples.py:363-368), (k,) for n == 1, 0-d for n == k == 1 (unpinned in the reference)."""
+    if n == 1 and k == 1:
+        return dists.reshape(()), corrs.reshape(())
+    return dists.reshape(-1), corrs.reshape(-1)
+
+
 _FN = {}
 
 
@@ -181,10 +186,13 @@ def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False
     Args:
         query_points : n by 3 array of representing a set of n points (each row is a point of dimension 3).
         dataset_points : m by 3 array of representing a set of m points (each row is a point of dimension 3).
-        k : the number of nearest neighbors to query per point.
+        k : the number of nearest neighbors to query per point. Any k > 0 (k <= 127: grid search; larger k: the reference's
+            kd-tree traversal run on the GPU, slower per query). If k exceeds the dataset size the trailing slots hold -1 / -1.0.
         squared_distances : If set to True, then return squared L2 distances. Default is False.
         max_points_per_leaf : leaf size of the reference's kd-tree. Does not change distances; it only fixes the order of exactly tied neighbours, which is reproduced.
         num_threads : OpenMP knob of the reference; accepted and ignored.
+
+    Limit of this implementation: point clouds of more than 2**27 - 16 (134,217,712) rows are rejected with a ValueError.
 
     Returns:
         dists : An (n, k)-shaped array such that `dists[i,k]` contains the k^th shortest L2 distance from the point `query_points[i, :]` to `dataset_points`
@@ -205,10 +213,8 @@ def k_nearest_neighbors(query_points, dataset_points, k, squared_distances=False
                               flags, d.stream, ctypes.addressof(st))
     _lib.check(rc)
     _record(st)
-    # npe::move(..., squeeze): a matrix with a singleton dimension comes back 1-D
-    # (pinned for k == 1 by tests/test_examples.py:363-368 of the reference).
     if k == 1 or n == 1:
-        return dists.reshape(-1), corrs.reshape(-1)
+        return _squeeze(dists, corrs, n, k)
     if not d.torch:
         q = np.asarray(query_points)
         if q.flags.f_contiguous and not q.flags.c_contiguous:      # EigenDenseLike keeps the query's storage order
@@ -337,7 +343,7 @@ class DatasetIndex:
         dists, corrs = index.k_nearest_neighbors(query_points, 8)       # same results as pcu.k_nearest_neighbors
 
     `dataset_points`: (m, 3) float32 / float64, numpy or CUDA/HIP torch tensor (copied; the caller's array can go away).
-    `k_hint` sizes the grid cells for the k that will mostly be asked for; any 1 <= k <= 127 is answered exactly.
+    `k_hint` sizes the grid cells for the k that will mostly be asked for; any k > 0 is answered exactly.
     Queries must have the dataset's dtype. The index lives on one GPU; call close() (or use `with`) to free it."""
 
     def __init__(self, dataset_points, k_hint=1):
@@ -388,7 +394,7 @@ class DatasetIndex:
             _lib.check(rc)
         _record(st)
         if k == 1 or n == 1:
-            return dists.reshape(-1), corrs.reshape(-1)
+            return _squeeze(dists, corrs, n, k)
         if not d.torch:
             q = np.asarray(query_points)
             if q.flags.f_contiguous and not q.flags.c_contiguous:

@@ -30,7 +30,6 @@ class Stats(ctypes.Structure):
 
 _lib = None
 _lock = threading.RLock()
-_ctxs = {}
 
 
 def _preload_hip_runtime():
@@ -82,6 +81,9 @@ def lib():
             getattr(L, "pcu_hip_debug_kd_tree_" + suf).argtypes = [vp, vp, i64, ci, vp, vp]
             getattr(L, "pcu_hip_index_create_" + suf).argtypes = [vp, vp, i64, ci, u, vp, ctypes.POINTER(ctypes.c_void_p)]
             getattr(L, "pcu_hip_index_knn_" + suf).argtypes = [vp, vp, vp, i64, ci, ci, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_hausdorff_batch_" + suf).argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_chamfer_batch_" + suf).argtypes = [vp, ci, vp, vp, vp, vp, ctypes.c_double, ci, vp, u, vp, vp]
+        L.pcu_hip_ctx_set_batch_lanes.argtypes = [vp, ci]
         L.pcu_hip_index_size.restype = ctypes.c_int64
         L.pcu_hip_index_size.argtypes = [vp]
         L.pcu_hip_index_destroy.argtypes = [vp]
@@ -105,34 +107,53 @@ def default_device():
 _tls = threading.local()
 
 
-def private_streams(on=True):
-    """Worker threads of a batch (point_cloud_utils_amd.batched) call this: their calls then run on their own
-    context's stream instead of torch's current stream, so independent pairs overlap on the GPU."""
-    _tls.private = bool(on)
+class _ThreadCtxs:
+    """The contexts one thread created. When the thread ends, its thread-local storage drops this object and the
+    contexts (streams, multi-GB workspaces) are destroyed with it instead of living until the process exits."""
+
+    def __init__(self):
+        self.by_device = {}
+
+    def __del__(self):
+        try:
+            import sys
+            if sys.is_finalizing():          # process exit: the HIP runtime reclaims everything itself
+                return
+            L = _lib
+            for h in self.by_device.values():
+                with _lock:
+                    _ctxs.discard(h.value)
+                if L is not None:
+                    L.pcu_hip_ctx_destroy(h)
+        except Exception:
+            pass
 
 
-def use_private_stream():
-    return getattr(_tls, "private", False)
+_ctxs = set()        # handles of all live contexts (diagnostics)
 
 
 def ctx(device=None):
     """Per-(device, thread) context (stream + grow-only workspace), created on first use. A context is not
-    thread-safe; giving every Python thread its own lets independent calls from a thread pool overlap."""
+    thread-safe; giving every Python thread its own lets independent calls from a thread pool overlap. A thread's
+    contexts are destroyed when the thread exits."""
     if device is None:
         device = default_device()
-    device = (int(device), threading.get_ident())
-    with _lock:
-        c = _ctxs.get(device)
-        if c is None:
-            L = lib()
-            h = ctypes.c_void_p()
-            rc = L.pcu_hip_ctx_create(int(device[0]), ctypes.byref(h))
-            if rc != 0:
-                raise RuntimeError(f"point_cloud_utils_amd: cannot create a GPU context on device {device[0]}: "
-                                   f"{last_error()} (this package has no CPU fallback)")
-            c = h
-            _ctxs[device] = c
-        return c
+    device = int(device)
+    mine = getattr(_tls, "ctxs", None)
+    if mine is None:
+        mine = _tls.ctxs = _ThreadCtxs()
+    c = mine.by_device.get(device)
+    if c is None:
+        L = lib()
+        h = ctypes.c_void_p()
+        rc = L.pcu_hip_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"point_cloud_utils_amd: cannot create a GPU context on device {device}: "
+                               f"{last_error()} (this package has no CPU fallback)")
+        c = mine.by_device[device] = h
+        with _lock:
+            _ctxs.add(h.value)
+    return c
 
 
 def set_cell_occupancy(points_per_cell, device=None):
@@ -146,13 +167,3 @@ def check(rc):
     if rc == ERR_INVALID:
         raise ValueError(msg)
     raise RuntimeError(f"libpcu_hip: {msg}")
-
-
-class _NoLock:
-    def __enter__(self): return self
-    def __exit__(self, *a): return False
-
-
-def lock():
-    """Contexts are per thread, so calls need no global lock (ctypes releases the GIL during the call)."""
-    return _NoLock()

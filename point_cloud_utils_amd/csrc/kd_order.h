@@ -671,26 +671,32 @@ struct KdSearchArgs {
     T* out_d; long long* out_i;
     void* stack; int stack_cap;         // per work item: stack_cap frames (tree depth + 2) in global memory
     int* error_flag;
+    // whole-cloud mode (k beyond the grid search's capacity, kd_search<T, true>): queries are the raw (nq, 3) rows, every block
+    // strides over them, the result set lives in dynamic LDS (rs_d == nullptr) or in a per-block global scratch of k slots
+    const T* qraw; int nq_raw;
+    T* rs_d; int* rs_i;
 };
 
 template <typename T>
 struct KdFrame { int node, other, idx, stage; T mindistsq, cut, dst; };
 
-// One WAVE per tied query: findNeighbors / computeInitialDistances / searchLevel / addPoint verbatim in behaviour
+// One WAVE per query: findNeighbors / computeInitialDistances / searchLevel / addPoint verbatim in behaviour
 // (nanoflann.hpp:1393-1418, :1164-1187, :1544-1624, :194-227). The control flow is wave-uniform (every lane runs the
 // same scalar recursion, unrolled onto an explicit stack); at a leaf the lanes fetch the leaf's points together and
 // evaluate their distances in parallel, then the points are offered to the result set one by one in vAcc order,
 // exactly as the reference's loop does.
-template <typename T>
-__global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
-    const int t = blockIdx.x, lane = threadIdx.x;
-    if (t >= *a.qcount_dev) return;
-    const Pt4<T> q = a.qsorted[a.qlist[t]];
+//   BIG = false: the tied queries of a grid search (k <= 128, result set in static LDS, lane 0 inserts serially).
+//   BIG = true : every query of a call whose k exceeds the grid search's capacity -- this IS the reference's algorithm, so the
+//                result is the reference's for any k (it accepts every k > 0, src/point_cloud_distance.cpp:133-135). The result
+//                set is addressed through generic pointers (LDS or global) and an insertion is done by the whole wave: the
+//                position is found by a uniform binary search, the tail is shifted 64 entries per step from the top down --
+//                the same final array as addPoint's serial shift loop.
+template <typename T, bool BIG>
+__device__ __forceinline__ void kd_search_one(const KdSearchArgs<T>& a, const int t, const int slot, const Pt4<T> q, const size_t out_row,
+                                              T* rd, int* ri, T* s_dists, T* s_vec) {
+    const int lane = threadIdx.x;
     const T vec[3] = {q.x, q.y, q.z};
     const int k = a.k;
-    __shared__ T rd[128]; __shared__ int ri[128];                       // KNNResultSet storage (k <= 128)
-    __shared__ T s_dists[3]; __shared__ T s_vec[3];                     // indexed by the split dimension: kept in LDS so
-                                                                        // that no select chain on a uniform index is generated
     int count = 0;
     if (lane == 0) rd[k - 1] = Limits<T>::max_v;                        // KNNResultSet::init (:176-183)
     __syncthreads();
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
     if (lane < 3) { s_dists[lane] = lane == 0 ? dists[0] : (lane == 1 ? dists[1] : dists[2]); s_vec[lane] = lane == 0 ? q.x : (lane == 1 ? q.y : q.z); }
     __syncthreads();
     typedef KdFrame<T> Frame;
-    Frame* st = reinterpret_cast<Frame*>(a.stack) + (size_t)t * a.stack_cap;     // recursion depth <= tree depth
+    Frame* st = reinterpret_cast<Frame*>(a.stack) + (size_t)slot * a.stack_cap;     // recursion depth <= tree depth
     int sp = 0;
     Frame f; f.node = 0; f.stage = 0; f.mindistsq = distsq; f.other = 0; f.idx = 0; f.cut = 0; f.dst = 0;
     // `f` is the frame on top (kept in registers, wave-uniform); st[] holds the frames below it.
@@ -729,14 +735,32 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
                     }
                     for (int e = 0; e < cnt; ++e) {
                         const T de = __shfl(d, e, 64); const int ie = __shfl(id, e, 64);
-                        if (de < worst_dist) {                          // addPoint (:194-227), lane 0 owns the arrays
-                            if (lane == 0) {
-                                int j;
-                                for (j = count; j > 0; --j) {
-                                    if (rd[j - 1] > de) { if (j < k) { rd[j] = rd[j - 1]; ri[j] = ri[j - 1]; } }
-                                    else break;
+                        if (de < worst_dist) {                          // addPoint (:194-227)
+                            if (!BIG) {                                 // lane 0 owns the arrays
+                                if (lane == 0) {
+                                    int j;
+                                    for (j = count; j > 0; --j) {
+                                        if (rd[j - 1] > de) { if (j < k) { rd[j] = rd[j - 1]; ri[j] = ri[j - 1]; } }
+                                        else break;
+                                    }
+                                    if (j < k) { rd[j] = de; ri[j] = ie; }
                                 }
-                                if (j < k) { rd[j] = de; ri[j] = ie; }
+                            } else {
+                                // where the serial loop stops: p = number of kept entries <= de (they form a prefix of the sorted array)
+                                int lo = 0, hi = count;
+                                while (lo < hi) { const int mid = (lo + hi) >> 1; if (rd[mid] <= de) lo = mid + 1; else hi = mid; }
+                                const int p = lo, top = min(count, k - 1);           // entries [p, top) move up by one slot
+                                for (int c = top; c > p; c -= 64) {
+                                    const int j = c - 1 - lane;
+                                    const bool on = j >= p;
+                                    T v = 0; int vi = 0;
+                                    if (on) { v = rd[j]; vi = ri[j]; }
+                                    __syncthreads();                    // (one wave per block) every read of this step precedes its writes
+                                    if (on) { rd[j + 1] = v; ri[j + 1] = vi; }
+                                    __syncthreads();
+                                }
+                                if (lane == 0 && p < k) { rd[p] = de; ri[p] = ie; }
+                                __syncthreads();
                             }
                             if (count < k) count++;
                         }
@@ -787,10 +811,38 @@ __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
         }
     }
     __syncthreads();
-    const size_t o = (size_t)(a.row_out ? (int)q.idx : a.qlist[t]) * (size_t)k;     // cell-ordered result rows unless row_out
+    const size_t o = out_row * (size_t)k;
     for (int j = lane; j < k; j += 64) {                                // src/point_cloud_distance.cpp:82-93
         if (j < count) { a.out_i[o + j] = ri[j]; a.out_d[o + j] = a.squared ? rd[j] : sqrt(rd[j]); }
         else { a.out_i[o + j] = -1; a.out_d[o + j] = (T)-1; }
+    }
+    (void)t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
+    const int t = blockIdx.x;
+    if (t >= *a.qcount_dev) return;
+    __shared__ T rd[128]; __shared__ int ri[128];                       // KNNResultSet storage (k <= 128)
+    __shared__ T s_dists[3]; __shared__ T s_vec[3];                     // indexed by the split dimension: kept in LDS so
+                                                                        // that no select chain on a uniform index is generated
+    const Pt4<T> q = a.qsorted[a.qlist[t]];
+    kd_search_one<T, false>(a, t, t, q, (size_t)(a.row_out ? (int)q.idx : a.qlist[t]), rd, ri, s_dists, s_vec);      // cell-ordered result rows unless row_out
+}
+
+// Whole-cloud mode: blocks (one wave each) stride over the raw query rows.
+template <typename T>
+__global__ __launch_bounds__(64) void k_kd_search_all(const KdSearchArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_rs[];
+    __shared__ T s_dists[3]; __shared__ T s_vec[3];
+    T* rd; int* ri;
+    if (a.rs_d) { rd = a.rs_d + (size_t)blockIdx.x * a.k; ri = a.rs_i + (size_t)blockIdx.x * a.k; }
+    else { rd = reinterpret_cast<T*>(s_rs); ri = reinterpret_cast<int*>(s_rs + (size_t)a.k * sizeof(T)); }
+    for (int t = blockIdx.x; t < a.nq_raw; t += gridDim.x) {
+        Pt4<T> q; q.x = a.qraw[3 * (size_t)t]; q.y = a.qraw[3 * (size_t)t + 1]; q.z = a.qraw[3 * (size_t)t + 2]; q.idx = t;
+        kd_search_one<T, true>(a, t, (int)blockIdx.x, q, (size_t)t, rd, ri, s_dists, s_vec);
+        if (*(volatile int*)a.error_flag) return;
+        __syncthreads();
     }
 }
 

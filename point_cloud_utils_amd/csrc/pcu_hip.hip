@@ -59,9 +59,27 @@ struct pcu_hip_ctx {
     char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
     struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[4];   // [type][with second planeSplit loop]
     bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
+    // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
+    // result block), created on first use
+    std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;
+    hipEvent_t batch_ev = nullptr;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Every entry point works on its context's device and leaves the calling thread's current HIP device as it found it
+// (a torch user who did torch.cuda.set_device(1) and then calls with numpy arrays -- device 0 -- must not find later torch
+// allocations on GPU 0).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 struct Arena {
     pcu_hip_ctx* c;
@@ -109,7 +127,6 @@ static int kd_ws_reserve(pcu_hip_ctx* c, size_t bytes) {
 
 static void ctx_end(pcu_hip_ctx* c);
 static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
-    HIP_TRY(hipSetDevice(c->device));
     ctx_end(c);                                 // drop overflow blocks left by a call that failed midway
     want_bytes += c->extra_hint;                // what earlier calls had to hipMalloc on top of their estimate (refitted / coarse grids)
     if (want_bytes > c->arena_cap) {
@@ -377,7 +394,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     if (K == 1 && use_gather && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
-        hipLaunchKernelGGL((k_search1_flat<T, false, 4>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
+        if (a.fuse == FUSE_SUM) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_SUM>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
+        else if (a.fuse == FUSE_ARGMAX) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_ARGMAX>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
+        else hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_NONE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -394,11 +413,13 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     return 0;
 }
 template <typename T>
-static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
+static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr, const FuseTail<T>* tail = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
     const int blocks = a.qcount_dev ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1); break;
+    FuseTail<T> ft; memset(&ft, 0, sizeof ft);
+    if (tail) ft = *tail;
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, ft); break;
     switch (K) {
         PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
@@ -442,6 +463,9 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     GridIndex<T> fine[2]; int n_fine = 0;       // finer dataset grids for the dense parts, finest first (unbalanced clouds only)
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
+    // fused epilogue (reduce.h): per-block partials of the k = 1 lane pass instead of result rows
+    int fuse = FUSE_NONE; int n_flat = 0;
+    double* f_sum = nullptr; T* f_max_v = nullptr; long long* f_max_k = nullptr;
 };
 
 template <typename T>
@@ -454,6 +478,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
     a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
+    a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     return a;
 }
 
@@ -461,7 +486,8 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
 // device-side lists: possible ties (radius 1, total order) and stragglers (radius 2). What is still uncertified after
 // that (list u2; next to nothing on balanced clouds) is finished by search_finish's host-driven loop.
 template <typename T>
-static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true) {
+static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true,
+                          const FuseTail<T>* tail = nullptr) {
     const SearchScratch<T>& sc = j.sc;
     const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
     if (zero_counters) HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
@@ -492,9 +518,10 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
         b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
-        if (launch_search_wave<T>(KL, b, s)) return -1;
+        if (launch_search_wave<T>(KL, b, s, nullptr, tail)) return -1;
         if (st) st->n_passes += 2 + j.n_fine;
     } else {
+        if (tail) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
         if (j.skew_check) b.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
@@ -512,9 +539,12 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 // (each direction keeps its own lists and counters). Falls back to two search_enqueue calls when a direction does not
 // take the k = 1 lane kernel (few queries, tile / generic kernels selected by environment).
 template <typename T>
-static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st) {
-    auto lane_k1 = [](const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0; };
-    if (!(lane_k1(j0) && lane_k1(j1) && use_gather_kernels() && use_k1_kernel())) {
+static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_gather_kernels() && use_k1_kernel(); }
+template <typename T>
+static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st,
+                               const FuseTail<T>* tail = nullptr) {
+    if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
+        if (tail) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue without the paired k = 1 pass");
         if (search_enqueue(c, s, j0, st, /*zero_counters=*/false)) return -1;
         return search_enqueue(c, s, j1, st, false);
     }
@@ -537,7 +567,7 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
     if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
     if (launch_search_fast<T>(1, a[0], j0.qidx.n, s, true, &a[1], j1.qidx.n)) return -1;
     if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
-    if (launch_search_wave<T>(2, b[0], s, &b[1])) return -1;
+    if (launch_search_wave<T>(2, b[0], s, &b[1], tail)) return -1;
     if (st) st->n_passes += 4;
     return 0;
 }
@@ -683,6 +713,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         KdSearchArgs<T> a;
         a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
         a.k = j.k; a.squared = j.squared ? 1 : 0; a.row_out = j.row_out ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
+        a.qraw = nullptr; a.nq_raw = 0; a.rs_d = nullptr; a.rs_i = nullptr;
         KdFrame<T>* frames = nullptr;
         a.stack_cap = levels + 2;
         if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
@@ -856,6 +887,70 @@ template <typename T> static const GridIndex<T>& index_grid(const pcu_hip_index*
 template <> const GridIndex<float>& index_grid<float>(const pcu_hip_index* p) { return p->g32; }
 template <> const GridIndex<double>& index_grid<double>(const pcu_hip_index* p) { return p->g64; }
 
+// k beyond the grid search's capacity (k > 127): the reference's own algorithm for every query -- its kd-tree, rebuilt on the GPU
+// (kd_order.h), and its traversal with a wave-cooperative result set of k slots (k_kd_search_all). Any k > 0 is answered, as
+// the reference does (src/point_cloud_distance.cpp:133-135); slots beyond the dataset size are padded (-1, -1.0) (:90-93).
+template <typename T>
+static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
+                     T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx) {
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
+    if (st) memset(st, 0, sizeof *st);
+    c->time_phases = false; c->time_kernels = false;
+    const size_t slot_bytes = (size_t)k * (sizeof(T) + 4);
+    const bool rs_lds = slot_bytes <= 64 * 1024;
+    int grid = (int)std::min<int64_t>(nq, 8192);
+    if (!rs_lds) grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)1 << 30) / slot_bytes));
+    const size_t out_bytes = align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);
+    size_t need = (pidx ? 0 : index_bytes<T>(nr, 2.0)) + (rs_lds ? 0 : 2 * align_up((size_t)grid * slot_bytes, 256)) +
+                  align_up((size_t)grid * 512 * sizeof(KdFrame<T>), 256) + 65536;
+    if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + (pidx ? 0 : align_up((size_t)nr * 3 * sizeof(T), 256)) + out_bytes;
+    if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T *dq, *dr;
+        if ((rc = stage_in(ar, query, nq, on_dev, s, &dq))) break;
+        if (pidx) dr = static_cast<const T*>(pidx->pts);
+        else if ((rc = stage_in(ar, dataset, nr, on_dev, s, &dr))) break;
+        T* dd = out_d; long long* di = (long long*)out_i;
+        if (!on_dev) { if ((rc = aalloc(ar, &dd, (size_t)nq * k))) break; if ((rc = aalloc(ar, &di, (size_t)nq * k))) break; }
+        GridIndex<T> gi;                          // only its exact bounding box is used (root of the kd-tree)
+        if (pidx) gi = index_grid<T>(pidx);
+        else { if ((rc = index_alloc(ar, gi, nr, 2.0))) break; if ((rc = index_build(gi, dr, 2.0, s))) break; if (st) st->n_grid_builds = 1; }
+        KdBuild<T> b; int* err = nullptr; int levels = 0;
+        if ((rc = kd_build_device(c, ar, s, dr, (int)nr, gi.gp, max_leaf > 0 ? max_leaf : 10, b, &err, &levels, nullptr))) break;
+        KdSearchArgs<T> a;
+        a.E = b.E; a.nodes = b.nodes; a.qsorted = nullptr; a.qlist = nullptr; a.qcount_dev = nullptr;
+        a.k = k; a.squared = squared ? 1 : 0; a.row_out = 1; a.out_d = dd; a.out_i = di; a.error_flag = err;
+        a.qraw = dq; a.nq_raw = (int)nq; a.rs_d = nullptr; a.rs_i = nullptr;
+        if (!rs_lds && ((rc = aalloc(ar, &a.rs_d, (size_t)grid * k)) || (rc = aalloc(ar, &a.rs_i, (size_t)grid * k)))) break;
+        KdFrame<T>* frames = nullptr;
+        a.stack_cap = levels + 2;
+        if ((rc = aalloc(ar, &frames, (size_t)grid * a.stack_cap))) break;
+        a.stack = frames;
+        static bool attr_set[2] = {false, false};
+        const int ti = sizeof(T) == 4 ? 0 : 1;
+        if (!attr_set[ti]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_search_all<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_set[ti] = true;
+        }
+        hipLaunchKernelGGL(k_kd_search_all<T>, dim3(grid), dim3(64), rs_lds ? slot_bytes : 0, s, a);
+        HIP_TRY(hipGetLastError());
+        int herr = 0;
+        HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!on_dev) {
+            HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        if (herr) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: kd traversal exceeded the tree depth (%d)", levels); break; }
+        if (st) { st->n_queries = nq; st->n_passes = 1; }
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+
 template <typename T>
 static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
                     T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx = nullptr) {
@@ -867,7 +962,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     }
     if (k <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid value for k (%d) must be greater than 0.", k);
     if (validate_sizes(nq, nr, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
-    if (k > kMaxK) return fail(PCU_HIP_ERR_INVALID, "k = %d > %d is not supported by the gfx950 path yet", k, kMaxK);
+    if (k > kMaxK) return knn_big_k<T>(c, query, nq, dataset, nr, k, max_leaf, out_d, out_i, flags, stream, st, pidx);
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
@@ -943,29 +1038,52 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
 // Shared front end of hausdorff / chamfer: both clouds indexed once; x->y and y->x searches with k = 1, both
 // enqueued back to back (each direction owns its lists and counters), epilogues enqueued behind them, ONE
 // stream synchronisation for the whole call unless some query needs the host-driven coarse-grid loop.
+//
+// Fused calls (Chamfer p = 2 without indices, Hausdorff; reduce.h "fused epilogues"): the searches reduce on the fly and the
+// wave-per-query launch ends the call, so a step is index build + 2 launches and no result rows exist. Whenever the fused
+// attempt cannot stand -- the dataset grid is unbalanced (refit path), some query is still uncertified after radius 2, or
+// (Hausdorff) the arg-max row has exactly tied neighbours whose order matters -- the call is redone through the row-based
+// path below, which handles all of that.
+struct CallBlock {               // one per call, zeroed by the first index-build launch
+    ResultBlock rb;              // pad[0] = epilogue ticket, pad[2..3] = tie bit of the fused arg-max winner per direction
+    unsigned long long limbs[2][kAccLimbs];     // exact sums of the wave-per-query pass (reduce.h)
+    double special[2];
+};
 template <typename T>
 struct PairState {
     const T *dx = nullptr, *dy = nullptr;
     SearchJob<T> xy, yx;                                // x rows searched in y / y rows searched in x
     T* pv = nullptr; long long* pi = nullptr; double* pd = nullptr;   // reduction partials (per direction: 2 x kRedBlocks)
     T* res_v = nullptr; long long* res_ij = nullptr; double* res_s = nullptr;
-    ResultBlock* rb = nullptr;
+    ResultBlock* rb = nullptr; CallBlock* cb = nullptr;
     bool two = true;
+    int fuse = FUSE_NONE; FuseTail<T> tail;             // fused attempt (tail: arguments of the launch that ends the call)
+    int* tie_hit = nullptr;
 };
 template <typename T>
 static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
     size_t b = index_bytes<T>(nx, occ) + index_bytes<T>(ny, occ) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
                align_up((size_t)nx * sizeof(T), 256) + align_up((size_t)ny * sizeof(T), 256) +
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
-               6 * align_up((size_t)kRedBlocks * 8, 256) + 8192;
+               6 * align_up((size_t)kRedBlocks * 8, 256) + 8192 +
+               3 * (align_up((size_t)grid8((int)nx, kBlock) * 8, 256) + align_up((size_t)grid8((int)ny, kBlock) * 8, 256)) +
+               2 * align_up((size_t)2 * kWaveBlocks * 8, 256) + align_up(sizeof(CallBlock), 256) + 1024;
     if (!on_dev) b += align_up((size_t)nx * 3 * sizeof(T), 256) + align_up((size_t)ny * 3 * sizeof(T), 256) +
                       align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256);
     return b;
 }
 template <typename T>
+static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, hipStream_t s2, PairState<T>& P, pcu_hip_stats* st) {
+    const FuseTail<T>* tail = P.fuse ? &P.tail : nullptr;
+    if (P.two && s2 == s) return search_enqueue_pair(c, s, P.xy, P.yx, st, tail);
+    if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false, P.two ? nullptr : tail)) return -1;
+    if (P.two && search_enqueue(c, s2, P.yx, st, false)) return -1;
+    return 0;
+}
+template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
                       bool squared, double occ, bool want_pos_x, bool want_pos_y, PairState<T>& P, Timer& tm,
-                      pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx) {
+                      pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx, int fuse_mode = FUSE_NONE) {
     P.two = two_sided;
     P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = tie_order_xy; P.yx.tie_order = tie_order_yx;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
@@ -975,31 +1093,48 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
-    if (aalloc(ar, &P.rb, 1)) return -1;
+    if (aalloc(ar, &P.cb, 1)) return -1;
+    P.rb = &P.cb->rb;
     if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
     if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
     if (aalloc(ar, &P.xy.out_i, (size_t)nx) || aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
+    if (aalloc(ar, &P.tie_hit, 16)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
-    tm.mark(0);
     // fork: cloud y is indexed on the aux stream while cloud x is indexed on s
     // (measured: the passes are throughput-bound, so the overlap only buys ~3 %; off unless PCU_HIP_TWO_STREAMS is set)
     hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
+    // fused attempt: only when every direction takes the k = 1 lane-per-query kernel on one stream
+    static const bool no_fuse = getenv("PCU_HIP_NO_FUSE") != nullptr;
+    P.fuse = FUSE_NONE;
+    if (fuse_mode != FUSE_NONE && !no_fuse && s2 == s && lane_k1_job(P.xy) && (!two_sided || lane_k1_job(P.yx))) {
+        P.fuse = fuse_mode;
+        FuseTail<T>& t = P.tail; memset(&t, 0, sizeof t);
+        t.mode = fuse_mode;
+        for (int d = 0; d < (two_sided ? 2 : 1); ++d) {
+            SearchJob<T>& J = d ? P.yx : P.xy;
+            J.fuse = fuse_mode; J.n_flat = grid8(J.qidx.n, kBlock);
+            if (aalloc(ar, &J.f_sum, (size_t)J.n_flat) || aalloc(ar, &J.f_max_v, (size_t)J.n_flat) || aalloc(ar, &J.f_max_k, (size_t)J.n_flat)) return -1;
+            t.flat_sum[d] = J.f_sum; t.flat_v[d] = J.f_max_v; t.flat_k[d] = J.f_max_k; t.nflat[d] = J.n_flat;
+        }
+        if (aalloc(ar, &t.wv, (size_t)2 * kWaveBlocks) || aalloc(ar, &t.wk, (size_t)2 * kWaveBlocks)) return -1;
+        t.limbs = &P.cb->limbs[0][0]; t.special = P.cb->special;
+        t.ticket = reinterpret_cast<unsigned*>(P.rb->pad);
+        t.out_sums = P.rb->sums; t.out_v = P.res_v; t.out_ij = P.rb->ij; t.out_tie = P.rb->pad + 2;
+        t.result_block = reinterpret_cast<const int*>(P.rb); t.host_block = c->h_pinned; t.seq = ++c->seq;
+    }
+    tm.mark(0);
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
-    // (the first build's first kernel also zeroes the call's result block: both directions' counters + the epilogue's ticket)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, false, P.rb, (int)(sizeof(ResultBlock) / 4))) return -1; }
-    else if (index_build(ix, P.dx, occ, s, false, P.rb, (int)(sizeof(ResultBlock) / 4)) || index_build(iy, P.dy, occ, s2)) return -1;
+    // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, false, P.cb, (int)(sizeof(CallBlock) / 4))) return -1; }
+    else if (index_build(ix, P.dx, occ, s, false, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
     }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
-    if (two_sided && s2 == s) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
-    else {
-        if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
-        if (two_sided && search_enqueue(c, s2, P.yx, st, false)) return -1;
-    }
+    if (pair_search_enqueue(c, s, s2, P, st)) return -1;
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[3], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[3], 0)); }   // join
     tm.mark(2);
     return 0;
@@ -1021,6 +1156,23 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
     HIP_TRY(hipStreamSynchronize(s));
     if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) return fail(PCU_HIP_ERR_RUNTIME, "internal: the epilogue kernel did not deliver its result block");
     return 0;
+}
+// A fused attempt stands when nothing needs the row-based machinery (see the head of this section).
+template <typename T>
+static bool fused_ok(const PairState<T>& P, const ResultBlock& h, bool tie_matters) {
+    for (int d = 0; d < (P.two ? 2 : 1); ++d) {
+        if (h.counters[d][C_SKEW] || h.counters[d][C_U2] > 0) return false;
+        if (tie_matters && P.fuse == FUSE_ARGMAX && h.pad[2 + d]) return false;
+    }
+    return true;
+}
+// Redo a fused call's searches through the row-based path (everything the fused attempt left behind is reset).
+template <typename T>
+static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
+    P.fuse = FUSE_NONE; P.xy.fuse = P.yx.fuse = FUSE_NONE;
+    HIP_TRY(hipMemsetAsync(P.cb, 0, sizeof(CallBlock), s));
+    if (st) { st->n_passes = 0; }
+    return pair_search_enqueue(c, s, s, P, st);
 }
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
 template <typename T>
@@ -1051,9 +1203,21 @@ static int argmax_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, bool t
     return 0;
 }
 
+// A two-sided (or one-sided) k = 1 call between its enqueue half and its finish half. The batch entry points keep one of
+// these in flight per lane (pcu_hip_ctx) so that the short kernels of independent pairs overlap on the GPU.
 template <typename T>
-static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided, int max_leaf,
-                          T* out_d, int64_t* out_i, int64_t* out_j, unsigned flags, void* stream, pcu_hip_stats* st) {
+struct PendingPair {
+    PairState<T> P;
+    Arena ar; Timer tm; hipStream_t s = nullptr;
+    const T *x = nullptr, *y = nullptr; int64_t nx = 0, ny = 0;
+    bool on_dev = false, squared = false, two_sided = true;
+    unsigned flags = 0; int max_leaf = 10; pcu_hip_stats* st = nullptr;
+    double p_norm = 2.0; int64_t *out_cxy = nullptr, *out_cyx = nullptr;      // chamfer
+};
+
+template <typename T>
+static int hausdorff_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided, int max_leaf,
+                           unsigned flags, void* stream, pcu_hip_stats* st, PendingPair<T>& pp) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "source", "targets")) return PCU_HIP_ERR_INVALID;
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
@@ -1062,50 +1226,83 @@ static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, in
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
-    Arena ar{c}; Timer tm{c, s, st};
+    pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
+    pp.on_dev = on_dev; pp.squared = squared; pp.two_sided = two_sided; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ, false, false, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
+    if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
+    return 0;
+}
+template <typename T>
+static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* out_i, int64_t* out_j) {
+    PairState<T>& P = pp.P; Arena& ar = pp.ar; Timer& tm = pp.tm; hipStream_t s = pp.s; pcu_hip_stats* st = pp.st;
+    const bool two_sided = pp.two_sided; const unsigned flags = pp.flags;
+    const bool tie_matters = !(flags & PCU_HIP_NO_TIE_ORDER);
     int rc = 0;
     do {
-        PairState<T> P;
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, squared, occ, false, false, P, tm, st, two_sided, max_leaf, false, false))) break;
         ResultBlock host;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
+        bool done = false;
+        if (P.fuse) {
             tm.mark(3);
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
-            else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
+            if ((rc = wait_result_block(c, s))) break;
+            memcpy(&host, c->h_pinned, sizeof host);
+            if (fused_ok(P, host, tie_matters)) {
+                for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
+                done = true;
+            } else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
-        if (rc) break;
-        // The value never depends on the order of exact ties, and (i, j) only does if the arg-max source row i itself
-        // has tied nearest neighbours: only then is that direction's tie order resolved (kd_order.h) and j re-read.
-        if (!(flags & PCU_HIP_NO_TIE_ORDER)) {
-            bool redo = false;
-            for (int dir = 0; dir < (two_sided ? 2 : 1) && !rc; ++dir) {
-                SearchJob<T>& J = dir ? P.yx : P.xy;
-                if (J.n_tt <= 0) continue;
-                std::vector<int> tq((size_t)J.n_tt);
-                HIP_TRY(hipMemcpy(tq.data(), J.sc.tt, (size_t)J.n_tt * sizeof(int), hipMemcpyDeviceToHost));
-                bool hit = false;
-                for (int qpos : tq) {
-                    Pt4<T> e; HIP_TRY(hipMemcpy(&e, J.qidx.sorted + qpos, sizeof e, hipMemcpyDeviceToHost));
-                    if ((long long)e.idx == host.ij[2 * dir]) { hit = true; break; }
-                }
-                if (hit) { if (tie_order_resolve(c, ar, s, J, J.n_tt, st)) { rc = -1; break; } redo = true; }
+        if (!done) {
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
+                tm.mark(3);
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
+                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
-            if (redo) {
-                if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
-                HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+            // The value never depends on the order of exact ties, and (i, j) only does if the arg-max source row i itself
+            // has tied nearest neighbours: only then is that direction's tie order resolved (kd_order.h) and j re-read.
+            // Whether row i is in a direction's true-tie list is checked on the device (one launch, one 4-byte read-back).
+            if (tie_matters && (P.xy.n_tt > 0 || (two_sided && P.yx.n_tt > 0))) {
+                HIP_TRY(hipMemsetAsync(P.tie_hit, 0, 2 * sizeof(int), s));
+                for (int dir = 0; dir < (two_sided ? 2 : 1); ++dir) {
+                    SearchJob<T>& J = dir ? P.yx : P.xy;
+                    if (J.n_tt <= 0) continue;
+                    hipLaunchKernelGGL(k_tie_hit<T>, dim3(std::min((J.n_tt + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, s,
+                                       J.sc.tt, J.n_tt, J.qidx.sorted, P.res_ij + 2 * dir, P.tie_hit + dir);
+                }
+                HIP_TRY(hipGetLastError());
+                int hit[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(hit, P.tie_hit, sizeof hit, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                memcpy(&host, c->h_pinned, sizeof host);
+                bool redo = false;
+                for (int dir = 0; dir < (two_sided ? 2 : 1) && !rc; ++dir) {
+                    SearchJob<T>& J = dir ? P.yx : P.xy;
+                    if (!hit[dir]) continue;
+                    if (tie_order_resolve(c, ar, s, J, J.n_tt, st)) { rc = -1; break; }
+                    redo = true;
+                }
+                if (rc) break;
+                if (redo) {
+                    if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
+                    HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    memcpy(&host, c->h_pinned, sizeof host);
+                }
             }
         }
         const T* hv = reinterpret_cast<const T*>(host.vals); const long long* hij = host.ij;
         const int nres = two_sided ? 2 : 1;
         for (int r = 0; r < nres; ++r) { out_d[r] = hv[r]; out_i[r] = hij[2 * r]; out_j[r] = hij[2 * r + 1]; }
-        if (st) { st->n_queries = two_sided ? nx + ny : nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
+        if (st) { st->n_queries = two_sided ? pp.nx + pp.ny : pp.nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename T>
+static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided, int max_leaf,
+                          T* out_d, int64_t* out_i, int64_t* out_j, unsigned flags, void* stream, pcu_hip_stats* st) {
+    PendingPair<T> pp;
+    if (int rc = hausdorff_begin(c, x, nx, y, ny, two_sided, max_leaf, flags, stream, st, pp)) return rc;
+    return hausdorff_end(c, pp, out_d, out_i, out_j);
 }
 
 static int pcode_of(double p) {
@@ -1117,8 +1314,8 @@ static int pcode_of(double p) {
 }
 
 template <typename T>
-static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf, double* out_mean2,
-                        int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st) {
+static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf,
+                         int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st, PendingPair<T>& pp) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
     if (isnan(p_norm)) return fail(PCU_HIP_ERR_INVALID, "p_norm is NaN");
@@ -1128,50 +1325,139 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
-    Arena ar{c}; Timer tm{c, s, st};
+    pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
+    pp.on_dev = on_dev; pp.two_sided = true; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
+    pp.p_norm = p_norm; pp.out_cxy = out_cxy; pp.out_cyx = out_cyx;
+    // Which of two exactly tied neighbours is picked changes a direction's contribution only through the returned
+    // indices, or through a p != 2 norm of the difference vector; the p = 2 value is the tied distance itself.
+    const bool tie_any = !(flags & PCU_HIP_NO_TIE_ORDER);
+    const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
+    // p = 2 without indices: the value is the sum of the nearest-neighbour distances -> fused epilogue, no result rows
+    const int fuse = (p_norm == 2.0 && !out_cxy && !out_cyx) ? FUSE_SUM : FUSE_NONE;
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, out_cxy != nullptr, out_cyx != nullptr, pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
+    if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
+    return 0;
+}
+template <typename T>
+static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
+    PairState<T>& P = pp.P; Arena& ar = pp.ar; Timer& tm = pp.tm; hipStream_t s = pp.s; pcu_hip_stats* st = pp.st;
+    const int64_t nx = pp.nx, ny = pp.ny; const bool on_dev = pp.on_dev;
+    int64_t *out_cxy = pp.out_cxy, *out_cyx = pp.out_cyx; const double p_norm = pp.p_norm;
     int rc = 0;
     do {
-        PairState<T> P;
-        long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
-        long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
-        // Which of two exactly tied neighbours is picked changes a direction's contribution only through the returned
-        // indices, or through a p != 2 norm of the difference vector; the p = 2 value is the tied distance itself.
-        const bool tie_any = !(flags & PCU_HIP_NO_TIE_ORDER);
-        const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
-        if ((rc = pair_setup(c, ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, out_cxy != nullptr, out_cyx != nullptr, P, tm, st, true, max_leaf, tie_xy, tie_yx))) break;
-        // row-ordered correspondences: straight into the caller's device arrays, or via a staging buffer
-        long long *dst_xy = ext_xy, *dst_yx = ext_yx;
-        if (!on_dev && out_cxy && (rc = aalloc(ar, &dst_xy, (size_t)nx))) break;
-        if (!on_dev && out_cyx && (rc = aalloc(ar, &dst_yx, (size_t)ny))) break;
-        const int pc = pcode_of(p_norm);
-        // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
-        const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
         ResultBlock host;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
-            if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
-            // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
-            const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx}, sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby};
-            hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
-                               reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
-            HIP_TRY(hipGetLastError());
+        bool done = false;
+        if (P.fuse) {
             tm.mark(3);
-            if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }
-            else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
+            if ((rc = wait_result_block(c, s))) break;
+            memcpy(&host, c->h_pinned, sizeof host);
+            if (fused_ok(P, host, false)) {
+                for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
+                done = true;
+            } else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
-        if (rc) break;
+        if (!done) {
+            long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
+            long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
+            // row-ordered correspondences: straight into the caller's device arrays, or via a staging buffer
+            long long *dst_xy = ext_xy, *dst_yx = ext_yx;
+            if (!on_dev && out_cxy && (rc = aalloc(ar, &dst_xy, (size_t)nx))) break;
+            if (!on_dev && out_cyx && (rc = aalloc(ar, &dst_yx, (size_t)ny))) break;
+            const int pc = pcode_of(p_norm);
+            // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
+            const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
+                if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
+                // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
+                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx}, sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby};
+                hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
+                                   reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
+                HIP_TRY(hipGetLastError());
+                tm.mark(3);
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }
+                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
+            }
+            if (rc) break;
+            if (!on_dev) {
+                if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, dst_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+                if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, dst_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+        }
         const double* hs = host.sums;
-        if (!on_dev) {
-            if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, dst_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
-            if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, dst_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
         out_mean2[0] = hs[0] / (double)nx;
         out_mean2[1] = hs[1] / (double)ny;
         if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename T>
+static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf, double* out_mean2,
+                        int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st) {
+    PendingPair<T> pp;
+    if (int rc = chamfer_begin(c, x, nx, y, ny, p_norm, max_leaf, out_cxy, out_cyx, flags, stream, st, pp)) return rc;
+    return chamfer_end(c, pp, out_mean2);
+}
+
+
+// ------------------------------------------------------------------------------------------------ batches of pairs
+// BASELINE config 4 (256 independent 256k-vs-256k pairs): clouds this small leave every kernel at the launch floor, so a
+// batch keeps several pairs in flight, each on a lane of its own (stream + workspace + pinned result block): the fused calls
+// above need no host decision between their enqueue and their result, so the host enqueues pair p + 1 .. p + L - 1 while
+// pair p runs and the short kernels of different pairs overlap on the GPU. Results are written in pair order.
+static int batch_lanes(pcu_hip_ctx* c, int n_pairs, void* stream, unsigned flags) {
+    const int want = std::max(1, std::min(std::min(c->n_lanes_wanted, 16), n_pairs));
+    while ((int)c->lanes.size() < want) {
+        pcu_hip_ctx* l = nullptr;
+        if (pcu_hip_ctx_create(c->device, &l)) return -1;
+        l->occupancy = c->occupancy;
+        c->lanes.push_back(l);
+    }
+    for (pcu_hip_ctx* l : c->lanes) l->occupancy = c->occupancy;
+    // inputs produced on the caller's stream must be complete before a lane reads them
+    if ((flags & PCU_HIP_PTRS_ON_DEVICE) && (stream || (flags & PCU_HIP_STREAM_GIVEN))) {
+        if (!c->batch_ev) HIP_TRY(hipEventCreateWithFlags(&c->batch_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->batch_ev, (hipStream_t)stream));
+        for (int i = 0; i < want; ++i) HIP_TRY(hipStreamWaitEvent(c->lanes[i]->own_stream, c->batch_ev, 0));
+    }
+    return want;
+}
+static void stats_add(pcu_hip_stats* tot, const pcu_hip_stats& s) {
+    if (!tot) return;
+    tot->n_queries += s.n_queries; tot->n_escalated += s.n_escalated; tot->n_tie_flagged += s.n_tie_flagged; tot->n_tie_true += s.n_tie_true;
+    tot->n_passes += s.n_passes; tot->n_grid_builds += s.n_grid_builds;
+}
+template <typename T, typename Begin, typename End>
+static int batch_run(pcu_hip_ctx* c, int n_pairs, unsigned flags, void* stream, pcu_hip_stats* st, Begin begin, End end) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (n_pairs < 0) return fail(PCU_HIP_ERR_INVALID, "negative number of pairs");
+    if (st) memset(st, 0, sizeof *st);
+    if (n_pairs == 0) return 0;
+    const int L = batch_lanes(c, n_pairs, stream, flags);
+    if (L < 0) return PCU_HIP_ERR_RUNTIME;
+    std::vector<PendingPair<T>> pend((size_t)L);
+    std::vector<pcu_hip_stats> lst((size_t)L);
+    std::vector<int> cur((size_t)L, -1);
+    const unsigned lflags = flags & ~(unsigned)(PCU_HIP_STREAM_GIVEN | PCU_HIP_TIME_PHASES | PCU_HIP_TIME_KERNELS);
+    int rc = 0; std::string err;
+    for (int p = 0; p < n_pairs + L; ++p) {
+        const int lane = p % L;
+        if (cur[lane] >= 0) {
+            const int r = end(c->lanes[lane], pend[lane], cur[lane]);
+            if (r && !rc) { rc = r; err = g_err; }
+            stats_add(st, lst[lane]);
+            cur[lane] = -1;
+        }
+        if (p < n_pairs && !rc) {
+            pend[lane] = PendingPair<T>();
+            const int r = begin(c->lanes[lane], pend[lane], p, lflags, &lst[lane]);
+            if (r) { rc = r; err = g_err; } else cur[lane] = p;
+        }
+    }
+    if (rc) g_err = err;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ persistent index
@@ -1193,7 +1479,6 @@ static int index_create_impl(pcu_hip_ctx* c, const T* dataset, int64_t nr, int k
     if (nr > 0x07fffff0ll) return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^27-16 rows are not supported");
     if (k_hint <= 0) k_hint = 1;
     if (k_hint > kMaxK) k_hint = kMaxK;
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     pcu_hip_index* p = new pcu_hip_index();
     p->elem_size = (int)sizeof(T); p->device = c->device; p->n = nr;
@@ -1265,7 +1550,7 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     int n = pcu_hip_device_count();
     if (n <= 0) return fail(PCU_HIP_ERR_NO_DEVICE, "no HIP device visible: the gfx950 path has no CPU fallback");
     if (device < 0 || device >= n) return fail(PCU_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dg(device);
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -1274,14 +1559,18 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into it
+    memset(c->h_pinned, 0, 64 * sizeof(int));
     *out_ctx = c;
     return 0;
 }
 void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     (void)hipDeviceSynchronize();
     ctx_end(c);
+    for (pcu_hip_ctx* l : c->lanes) pcu_hip_ctx_destroy(l);
+    c->lanes.clear();
+    if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     if (c->arena) (void)hipFree(c->arena);
     kd_graph_drop(c);
     if (c->kd_ws) (void)hipFree(c->kd_ws);
@@ -1297,47 +1586,75 @@ int pcu_hip_ctx_set_cell_occupancy(pcu_hip_ctx* c, double ppc) { if (!c) return 
 int64_t pcu_hip_ctx_workspace_bytes(pcu_hip_ctx* c) { return c ? (int64_t)c->arena_cap : 0; }
 
 int pcu_hip_knn_f32(pcu_hip_ctx* c, const float* q, int64_t nq, const float* r, int64_t nr, int k, int max_leaf, float* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<float>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
+                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return knn_impl<float>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
 int pcu_hip_knn_f64(pcu_hip_ctx* c, const double* q, int64_t nq, const double* r, int64_t nr, int k, int max_leaf, double* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { return knn_impl<double>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
+                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return knn_impl<double>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
 
 int pcu_hip_one_sided_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<float>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
 int pcu_hip_one_sided_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<double>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
 int pcu_hip_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<float>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
+                          unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<float>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
 int pcu_hip_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { return hausdorff_impl<double>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
+                          unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<double>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
 
 int pcu_hip_chamfer_f32(pcu_hip_ctx* c, const float* x, int64_t nx, const float* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<float>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+                        unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return chamfer_impl<float>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
 int pcu_hip_chamfer_f64(pcu_hip_ctx* c, const double* x, int64_t nx, const double* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { return chamfer_impl<double>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+                        unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return chamfer_impl<double>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
 
-int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
-int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
+#define PCU_BATCH_HAUSDORFF(SUF, T)                                                                                                         \
+int pcu_hip_hausdorff_batch_##SUF(pcu_hip_ctx* c, int n_pairs, const T* const* xs, const int64_t* nxs, const T* const* ys, const int64_t* nys,   \
+                                  int max_leaf, T* out_d2, int64_t* out_i2, int64_t* out_j2, unsigned flags, void* stream, pcu_hip_stats* st) {  \
+    DeviceGuard dg(c ? c->device : -1);                                                                                                     \
+    return batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p, unsigned lf, pcu_hip_stats* ls) { return hausdorff_begin<T>(l, xs[p], nxs[p], ys[p], nys[p], true, max_leaf, lf, nullptr, ls, pp); }, \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return hausdorff_end<T>(l, pp, out_d2 + 2 * (size_t)p, out_i2 + 2 * (size_t)p, out_j2 + 2 * (size_t)p); });        \
+}
+PCU_BATCH_HAUSDORFF(f32, float)
+PCU_BATCH_HAUSDORFF(f64, double)
+#undef PCU_BATCH_HAUSDORFF
+#define PCU_BATCH_CHAMFER(SUF, T)                                                                                                           \
+int pcu_hip_chamfer_batch_##SUF(pcu_hip_ctx* c, int n_pairs, const T* const* xs, const int64_t* nxs, const T* const* ys, const int64_t* nys,     \
+                                double p_norm, int max_leaf, double* out_mean2, unsigned flags, void* stream, pcu_hip_stats* st) {          \
+    DeviceGuard dg(c ? c->device : -1);                                                                                                     \
+    return batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p, unsigned lf, pcu_hip_stats* ls) { return chamfer_begin<T>(l, xs[p], nxs[p], ys[p], nys[p], p_norm, max_leaf, nullptr, nullptr, lf, nullptr, ls, pp); }, \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return chamfer_end<T>(l, pp, out_mean2 + 2 * (size_t)p); });                             \
+}
+PCU_BATCH_CHAMFER(f32, float)
+PCU_BATCH_CHAMFER(f64, double)
+#undef PCU_BATCH_CHAMFER
+int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
+
+int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
+int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
 
 int pcu_hip_index_create_f32(pcu_hip_ctx* c, const float* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
+    DeviceGuard dg(c ? c->device : -1);
     return index_create_impl<float>(c, r, nr, k_hint, flags, stream, out);
 }
 int pcu_hip_index_create_f64(pcu_hip_ctx* c, const double* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
+    DeviceGuard dg(c ? c->device : -1);
     return index_create_impl<double>(c, r, nr, k_hint, flags, stream, out);
 }
 int pcu_hip_index_knn_f32(pcu_hip_ctx* c, const pcu_hip_index* ix, const float* q, int64_t nq, int k, int max_leaf, float* od, int64_t* oi,
                           unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
+    DeviceGuard dg(c ? c->device : -1);
     return knn_impl<float>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
 }
 int pcu_hip_index_knn_f64(pcu_hip_ctx* c, const pcu_hip_index* ix, const double* q, int64_t nq, int k, int max_leaf, double* od, int64_t* oi,
                           unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
+    DeviceGuard dg(c ? c->device : -1);
     return knn_impl<double>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
 }
 int64_t pcu_hip_index_size(const pcu_hip_index* ix) { return ix ? ix->n : 0; }
 void pcu_hip_index_destroy(pcu_hip_index* ix) {
     if (!ix) return;
-    (void)hipSetDevice(ix->device);
+    DeviceGuard dg(ix->device);
     (void)hipDeviceSynchronize();
     index_free(ix);
 }

@@ -81,6 +81,74 @@ __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, 
     }
 }
 
+// ---- fused epilogues (search.h: k_search1_flat / k_search_wave with SearchArgs::fuse != 0) ---------------------------------
+// Chamfer (p = 2, no indices) and Hausdorff need one scalar (pair) per direction, not the per-query rows. In fused mode the
+// lane-per-query pass reduces its certified lanes' distances to ONE partial per block (fp64 sum, or arg-max) instead of
+// writing (d, idx) rows, the wave-per-query pass adds its few queries, and the block of that launch which finishes last folds
+// everything and hands the call's result block to the host: no rows written (-24 B per query of HBM writes and the re-read),
+// no separate epilogue launch.
+//
+// The wave-per-query pass takes its queries from device-side lists whose ORDER depends on the timing of atomics, so its
+// share of a floating-point sum would not be reproducible run to run. It is therefore accumulated EXACTLY: every value is
+// split into 32-bit limbs of a wide fixed-point number (bit 0 = 2^-1074) and each limb is added with an integer atomic into
+// its own 64-bit word (2^32 additions cannot overflow a word; carries are propagated once, by the fold). Integer addition
+// commutes, so the result does not depend on the order, and the fold's conversion back to double is deterministic.
+constexpr int kAccLimbs = 66;              // (2045 + 53 + 32) / 32 + 1: any finite double fits
+__device__ __forceinline__ void exact_add(unsigned long long* limbs, double* special, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned be = (unsigned)(b >> 52) & 0x7ffu;
+    if (be == 0x7ffu || (long long)b < 0) { atomicAdd(special, v); return; }         // inf / NaN (and, never here, negatives): their sum is order-independent as a class
+    const unsigned long long m = (b & 0x000fffffffffffffull) | (be ? 0x0010000000000000ull : 0ull);
+    if (m == 0) return;
+    const unsigned sh = be ? be - 1u : 0u;          // v = m * 2^(sh - 1074)
+    const unsigned L = sh >> 5, off = sh & 31u;
+    const unsigned long long lo64 = m << off, hi = off ? m >> (64u - off) : 0ull;      // the 85-bit value m << off
+    const unsigned long long w0 = lo64 & 0xffffffffull, w1 = lo64 >> 32, w2 = hi;
+    if (w0) atomicAdd(&limbs[L], w0);
+    if (w1) atomicAdd(&limbs[L + 1], w1);
+    if (w2) atomicAdd(&limbs[L + 2], w2);
+}
+// One thread: the accumulated value as a double (carries propagated in place, then summed from the top limb down).
+__device__ __noinline__ double exact_value(unsigned long long* limbs, const double* special) {
+    unsigned long long carry = 0;
+#pragma unroll 1
+    for (int i = 0; i < kAccLimbs; ++i) {
+        const unsigned long long v = __hip_atomic_load(&limbs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + carry;
+        __hip_atomic_store(&limbs[i], v & 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        carry = v >> 32;
+    }
+    double r = 0;
+#pragma unroll 1
+    for (int i = kAccLimbs - 1; i >= 0; --i) {
+        const unsigned long long v = __hip_atomic_load(&limbs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) r += ldexp((double)v, 32 * i - 1074);
+    }
+    return r + __hip_atomic_load(special, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+enum { FUSE_NONE = 0, FUSE_SUM = 1, FUSE_ARGMAX = 2 };
+// What the wave-per-query launch of a fused call needs to finish the call (by value, in its kernel arguments).
+template <typename T>
+struct FuseTail {
+    int mode;                                    // FUSE_*
+    const double* flat_sum[2]; const T* flat_v[2]; const long long* flat_k[2]; int nflat[2];   // the lane pass's per-block partials, per direction
+    double* wsum; T* wv; long long* wk;          // this launch's per-block partials, [direction][gridDim.x] (FUSE_ARGMAX)
+    unsigned long long* limbs; double* special;  // [direction][kAccLimbs], [direction]: exact sum of this launch's distances (FUSE_SUM)
+    unsigned* ticket;
+    double* out_sums; T* out_v; long long* out_ij; int* out_tie;      // fields of the call's result block
+    const int* result_block; int* host_block; unsigned seq;
+};
+
+// Hausdorff, row-based path: is the arg-max source row (ij[0], in the call's result block) one of the direction's queries
+// with a genuine tie? Only then does the returned j depend on the reference's tie order (pcu_hip.hip, hausdorff_end).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tie_hit(const int* __restrict__ tt, int n, const Pt4<T>* __restrict__ qsorted,
+                                                    const long long* __restrict__ ij, int* flag) {
+    const long long row = ij[0];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        if ((long long)qsorted[tt[i]].idx == row) *flag = 1;
+}
+
 __device__ __forceinline__ double block_sum(double s) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);

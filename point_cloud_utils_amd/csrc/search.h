@@ -26,6 +26,7 @@
 #pragma once
 #include "pcu_types.h"
 #include "grid.h"
+#include "reduce.h"
 
 namespace pcu {
 
@@ -55,6 +56,11 @@ struct SearchArgs {
     long long* out_i;               // (nq_total, kreq)  (k_unpermute restores the caller's row order when needed)
     int* unresolved; int* n_unresolved;
     int* ties;       int* n_ties;         // lane passes: possible tie; wave pass: genuine tie ("true ties")
+    // Fused epilogue (reduce.h, FUSE_*): instead of result rows the k = 1 lane pass writes ONE partial per block --
+    // FUSE_SUM: fp64 sum of its certified lanes' distances -> f_sum[block]; FUSE_ARGMAX: their arg-max -> f_max_v / f_max_k[block]
+    // (key = source row << 32 | tie bit 31 | dataset row). No rows are written and only deferred lanes enter the tie list.
+    int fuse;
+    double* f_sum; T* f_max_v; long long* f_max_k;
 };
 
 // Append `value` for lanes with `flag` set; one atomic per wave.
@@ -375,8 +381,8 @@ template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { retur
 // Register layout: the centre row's table is loaded and scanned first; only then are the other eight rows' tables fetched
 // (EARLY = false: one more dependent wait per wave, but their 32 registers are not live during the centre scan: 68 VGPRs
 // instead of 93, 7 waves per SIMD instead of 5). EARLY = true fetches them right away (79 VGPRs; measured equal).
-template <typename T, bool EARLY>
-__device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int bid, const int nblk) {
+template <typename T, bool EARLY, int FUSE>
+__device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int bid, const int nblk, bool& f_ok, T& f_v, long long& f_key) {
     __shared__ uint2 s_rng[8][kBlock];
     const int per = nblk >> 3;
     const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search (nblk and the side's first block: multiples of 8)
@@ -538,16 +544,37 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     }
     const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
     const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-    finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer);
+    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer); return; }
+    // fused epilogue: the lane's distance goes into the block's partial (kernel wrapper) instead of a result row
+    if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
+        wave_append(true, qpos, a.ties, a.n_ties);
+        return;
+    }
+    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const bool certified = best < lb;
+    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
+    f_ok = certified;
+    f_v = a.squared ? best : sqrt(best);
+    f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
 }
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
 template <typename T> struct SearchArgs2 { SearchArgs<T> a[2]; };
-template <typename T, bool EARLY, int MINW>
+template <typename T, bool EARLY, int MINW, int FUSE>
 __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2<T> p, int nb0) {
     // (the side's arguments are read through an index into the kernel-argument segment; selecting between two by-value
     // structs by reference makes the compiler copy the chosen one to scratch)
     const int side = (int)blockIdx.x >= nb0 ? 1 : 0;
-    search1_flat_body<T, EARLY>(p.a[side], side ? (int)blockIdx.x - nb0 : (int)blockIdx.x, side ? (int)gridDim.x - nb0 : nb0);
+    const int bid = side ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
+    bool ok = false; T v = (T)0; long long key = 0x7fffffffffffffffll;
+    search1_flat_body<T, EARLY, FUSE>(p.a[side], bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
+    if (FUSE == FUSE_SUM) {                     // one fp64 partial per block; lanes in a fixed order: reproducible
+        const double r = block_sum(ok ? (double)v : 0.0);
+        if (threadIdx.x == 0) p.a[side].f_sum[bid] = r;
+    } else if (FUSE == FUSE_ARGMAX) {           // first maximum by source row (Eigen's maxCoeff visits rows in order, strict '>')
+        T bv = ok ? v : -Limits<T>::max_v; long long bk = ok ? key : 0x7fffffffffffffffll;
+        block_argmax(bv, bk);
+        if (threadIdx.x == 0) { p.a[side].f_max_v[bid] = bv; p.a[side].f_max_k[bid] = bk; }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -690,8 +717,10 @@ template <typename T>
 __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d < d2 || (d == d2 && id < id2); }
 
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs) {
+__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const FuseTail<T> ft) {
     const int lane = threadIdx.x & 63;
+    T fbest_v[2] = {-Limits<T>::max_v, -Limits<T>::max_v};                         // fused arg-max: this wave's best per direction
+    long long fbest_k[2] = {0x7fffffffffffffffll, 0x7fffffffffffffffll};
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * kBlock) >> 6;
     // work items: job 0's list(s), then (two-sided calls) job 1's
@@ -795,7 +824,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         }
         const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
         const bool certified = kth < lb;
-        if (certified) {
+        if (certified && a.fuse != FUSE_NONE) {
+            // fused epilogue (k = 1): the query's distance joins the direction's exact sum / this wave's arg-max; no row, no tie list
+            const T v0 = (T)__shfl(a.squared ? my_d : sqrt(my_d), 0, 64);
+            const int i0 = __shfl(my_i, 0, 64);
+            if (a.fuse == FUSE_SUM) { if (lane == 0) exact_add(ft.limbs + (job1 ? kAccLimbs : 0), ft.special + (job1 ? 1 : 0), (double)v0); }
+            else argmax_combine(fbest_v[job1 ? 1 : 0], fbest_k[job1 ? 1 : 0], v0, ((long long)q.idx << 32) | (long long)((unsigned)i0 | (tie ? 0x80000000u : 0u)));
+        } else if (certified) {
             if (lane < kreq) {
                 const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)kreq + lane;
                 const bool found = my_i != 0x7fffffff;
@@ -812,6 +847,57 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         } else if (lane == 0) {
             a.unresolved[atomicAdd(a.n_unresolved, 1)] = qpos;
         }
+    }
+    if (ft.mode == FUSE_NONE) return;
+    // ---- fused epilogue: this launch ends the call. Per-block partials (arg-max) / exact limbs (sum) are complete when a block
+    // takes its ticket; the block that takes the last one folds them with the lane pass's per-block partials (written by the
+    // previous launch), fills the result block and hands it to the host (sequence word last, see k_pnorm_pair).
+    __shared__ T s_fv[2][kBlock / 64]; __shared__ long long s_fk[2][kBlock / 64];
+    __shared__ bool s_last;
+    const int wv_in_blk = threadIdx.x >> 6;
+    if (ft.mode == FUSE_ARGMAX && lane == 0) {
+        s_fv[0][wv_in_blk] = fbest_v[0]; s_fk[0][wv_in_blk] = fbest_k[0];
+        s_fv[1][wv_in_blk] = fbest_v[1]; s_fk[1][wv_in_blk] = fbest_k[1];
+    }
+    wait_stores();                               // this wave's limb atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ft.mode == FUSE_ARGMAX) {
+            for (int jb = 0; jb < njobs; ++jb) {
+                T v = s_fv[jb][0]; long long kk = s_fk[jb][0];
+                for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, kk, s_fv[jb][w], s_fk[jb][w]);
+                publish(&ft.wv[jb * (int)gridDim.x + (int)blockIdx.x], v); publish(&ft.wk[jb * (int)gridDim.x + (int)blockIdx.x], kk);
+            }
+            wait_stores();
+        }
+        s_last = take_ticket(ft.ticket, gridDim.x);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int jb = 0; jb < njobs; ++jb) {
+        if (ft.mode == FUSE_SUM) {
+            double acc = 0;
+            for (int i = threadIdx.x; i < ft.nflat[jb]; i += kBlock) acc += ft.flat_sum[jb][i];
+            __syncthreads();                     // block_sum's shared array is reused
+            const double r = block_sum(acc);
+            if (threadIdx.x == 0) ft.out_sums[jb] = r + exact_value(ft.limbs + jb * kAccLimbs, ft.special + jb);
+        } else {
+            T v = -Limits<T>::max_v; long long kk = 0x7fffffffffffffffll;
+            for (int i = threadIdx.x; i < ft.nflat[jb]; i += kBlock) argmax_combine(v, kk, ft.flat_v[jb][i], ft.flat_k[jb][i]);
+            for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) argmax_combine(v, kk, peek(&ft.wv[jb * (int)gridDim.x + i]), peek(&ft.wk[jb * (int)gridDim.x + i]));
+            block_argmax(v, kk);
+            if (threadIdx.x == 0) {
+                ft.out_v[jb] = v; ft.out_ij[2 * jb] = kk >> 32; ft.out_ij[2 * jb + 1] = kk & 0x7fffffffll;
+                ft.out_tie[jb] = (int)((kk >> 31) & 1ll);
+            }
+        }
+    }
+    if (threadIdx.x == 0) { *ft.ticket = 0u; wait_stores(); }
+    __syncthreads();
+    if (ft.host_block && threadIdx.x < 64) {
+        if (threadIdx.x < 63) ft.host_block[threadIdx.x] = peek(&ft.result_block[threadIdx.x]);
+        __threadfence_system();
+        if (threadIdx.x == 63) __hip_atomic_store(&ft.host_block[63], (int)ft.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

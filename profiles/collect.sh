@@ -1,19 +1,32 @@
 #!/bin/bash
 # Collects the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/<tag>_bench.json         bench.py line (with cpu_baseline)
+#   gpurun_out/<tag>_bench.json         bench.py line (with cpu_baseline + parity)
 #   gpurun_out/<tag>_trace/             rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/<tag>_pmc_fetch|write/   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, csv)
+#   gpurun_out/<tag>_pmc_<pass>/        rocprofv3 --pmc passes (separate runs, csv): fetch, write, tcc (raw request counters),
+#                                       sq (instruction mix, active lanes, scalar unit), sq2 (wave-cycle breakdown), ta, tcp
+#   gpurun_out/<tag>_calib_<pass>/      the same TCC passes over profiles/calib/calib_gather (known byte counts)
 # then `python profiles/postprocess.py <tag>` (CPU side) turns them into the tracked summaries under profiles/.
-TAG=${1:-r01}
+# Counter passes never carry trace domains other than --kernel-trace (gpurun refuses --pmc with sys/hip/hsa traces).
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
 python $ROOT/bench.py --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_sq -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum --output-format csv -d $OUT/${TAG}_pmc_ta -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_ta.log 2>&1
-rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/${TAG}_pmc_tcp -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_tcp.log 2>&1
-tail -c 1500 $OUT/${TAG}_bench.json
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity > $OUT/${TAG}_trace.log 2>&1
+pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass tcc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_HIT_sum
+pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE
+pass sq2 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE
+pass ta TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+if [ -x $ROOT/profiles/calib/calib_gather ]; then
+  C=$ROOT/profiles/calib/calib_gather
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_calib_fetch -- $C > $OUT/${TAG}_calib_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_calib_write -- $C > $OUT/${TAG}_calib_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum --output-format csv -d $OUT/${TAG}_calib_tcc -- $C > $OUT/${TAG}_calib_tcc.log 2>&1
+fi
+tail -c 2500 $OUT/${TAG}_bench.json

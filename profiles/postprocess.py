@@ -1,42 +1,92 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/<tag>_* (written by profiles/collect.sh on the GPU box) into tracked summaries:
-   profiles/<tag>_bench.json, profiles/<tag>_kernel_stats.txt, profiles/<tag>_pmc.txt, profiles/hbm_traffic.json"""
+   profiles/<tag>_bench.json, profiles/<tag>_kernel_stats.txt, profiles/<tag>_pmc.txt, profiles/<tag>_calib.txt,
+   profiles/hbm_traffic.json (read by bench.py: measured HBM bytes per launch + issue-side fractions of the dominant kernel)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
+N_SIMD, N_CU = 1024, 256          # MI355X: 256 CUs x 4 SIMD-32
 line = [l for l in open(os.path.join(G, f"{tag}_bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
 db = glob.glob(os.path.join(G, f"{tag}_trace", "*", "*.db"))[0]
 txt = subprocess.run([sys.executable, os.path.join(P, "summarize_rocprof.py"), db], capture_output=True, text=True).stdout
 open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w").write(txt.replace(ROOT + "/", ""))
-def pmc(d):
-    f = glob.glob(os.path.join(G, f"{tag}_pmc_{d}", "*", "*_counter_collection.csv"))[0]
+
+
+def pmc(prefix, d):
+    fs = glob.glob(os.path.join(G, f"{tag}_{prefix}_{d}", "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
+    if not fs:
+        return agg
+    for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].replace("void pcu::", "").split("(")[0].replace("pcu::", "")
         if k.startswith("k_"): agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
+
+
+# ---- calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (profiles/calib/calib_gather.hip: 1 GiB per kernel)
+GIB = float(1 << 30)
+cal = ["# profiles/calib/calib_gather: every kernel touches each 16-byte record of a 1 GiB array exactly once (true HBM bytes: 1 GiB)",
+       "# reported = counter x 1024 (FETCH_SIZE / WRITE_SIZE are in KB); factor = true bytes / reported bytes"]
+cf, cw, ct = pmc("calib", "fetch"), pmc("calib", "write"), pmc("calib", "tcc")
+factor = {}
+for k in sorted(set(cf) | set(cw)):
+    f = mean(cf[k].get("FETCH_SIZE", [])) * 1024; w = mean(cw[k].get("WRITE_SIZE", [])) * 1024
+    raw = "  ".join(f"{c}={mean(v):.4g}" for c, v in ct.get(k, {}).items())
+    if k.startswith("k_w"):
+        factor[k] = GIB / w if w else None
+        cal.append(f"{k:14s} WRITE_SIZE -> {w / GIB:6.3f} GiB reported, factor {factor[k]}   (FETCH_SIZE {f / GIB:.3f} GiB)  {raw}")
+    else:
+        factor[k] = GIB / f if f else None
+        cal.append(f"{k:14s} FETCH_SIZE -> {f / GIB:6.3f} GiB reported, factor {factor[k]}  {raw}")
+open(os.path.join(P, f"{tag}_calib.txt"), "w").write("\n".join(cal) + "\n")
+f_stream = factor.get("k_stream16") or 2.0          # coalesced reads (index-build passes)
+f_gather = factor.get("k_gather12") or factor.get("k_gather16") or f_stream      # per-lane record gathers (search kernels)
+w_stream = factor.get("k_wstream16") or 1.0
+w_scatter = factor.get("k_wscatter16") or w_stream
+
 out = ["# rocprofv3 --pmc passes (separate runs of `bench.py --steps 5 --warmup 2`), mean per dispatch",
-       "# FETCH_SIZE / WRITE_SIZE are in KB. gfx950 note (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128 B request,",
-       "# i.e. reports 1/2 of the bytes of coalesced reads (k_bbox_partial reads 12.0 MB: ~5,870 KB reported); WRITE_SIZE",
-       "# matched a known coalesced 16.0 MB write. hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024."]
-fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
-for extra_pass in ("ta", "tcp"):          # texture-addresser / L1 counters of the search kernels (optional passes)
-    try:
-        for k, cs in pmc(extra_pass).items():
-            for c, v in cs.items(): sq[k][c] = v
-    except Exception:
-        pass
+       f"# FETCH_SIZE / WRITE_SIZE are in KB. Calibrated on this box (profiles/{tag}_calib.txt): true bytes = reported x factor,",
+       f"#   coalesced reads x{f_stream:.3f}, 12/16-byte per-lane gathers x{f_gather:.3f}, coalesced writes x{w_stream:.3f}, scattered 16-byte writes x{w_scatter:.3f}.",
+       "# hbm_bytes = FETCH_SIZE*1024*f_read + WRITE_SIZE*1024*f_write with the gather factors for k_search*, the streaming ones otherwise."]
+fetch, write = pmc("pmc", "fetch"), pmc("pmc", "write")
+sq = pmc("pmc", "sq")
+for extra_pass in ("sq2", "tcc", "ta", "tcp"):
+    for k, cs in pmc("pmc", extra_pass).items():
+        for c, v in cs.items(): sq[k][c] = v
 traffic = {}
 for k in fetch:
-    f = sum(fetch[k]["FETCH_SIZE"]) / len(fetch[k]["FETCH_SIZE"]); w = sum(write[k]["WRITE_SIZE"]) / len(write[k]["WRITE_SIZE"]) if k in write else 0
-    traffic[k] = (2 * f + w) * 1024
-    extra = "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sq.get(k, {}).items())
-    out.append(f"{k:34s} n={len(fetch[k]['FETCH_SIZE']):3d} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} hbm_bytes={traffic[k]:.4g}  {extra}")
+    f = mean(fetch[k]["FETCH_SIZE"]); w = mean(write[k]["WRITE_SIZE"]) if k in write else 0
+    gather = k.startswith("k_search")
+    traffic[k] = f * 1024 * (f_gather if gather else f_stream) + w * 1024 * (w_scatter if k.startswith("k_bucket_scatter") else w_stream)
+    extra = "  ".join(f"{c}={mean(v):.4g}" for c, v in sorted(sq.get(k, {}).items()))
+    out.append(f"{k:40s} n={len(fetch[k]['FETCH_SIZE']):3d} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} hbm_bytes={traffic[k]:.4g}  {extra}")
 open(os.path.join(P, f"{tag}_pmc.txt"), "w").write("\n".join(out) + "\n")
-flat = [v for k, v in traffic.items() if k.startswith("k_search1_flat<float")]
-json.dump({"source": f"profiles/{tag}_pmc.txt", "k_search1_flat_f32_bytes_per_launch": flat[0] if flat else None,
-           "note": "one launch = both directions of the 1M-vs-1M Chamfer step; 2*FETCH_SIZE + WRITE_SIZE, see the header of the source file"},
-          open(os.path.join(P, "hbm_traffic.json"), "w"))
-print(line[:600]); print("\n".join(out[4:12]))
+
+dom = [k for k in traffic if k.startswith("k_search1_flat<float")]
+rep = {"source": f"profiles/{tag}_pmc.txt", "counters_source": f"profiles/{tag}_pmc.txt + profiles/{tag}_calib.txt",
+       "k_search1_flat_f32_bytes_per_launch": traffic[dom[0]] if dom else None,
+       "index_build_bytes_per_step": sum(v * (2 if k.startswith("k_bucket_sort") else 1) for k, v in traffic.items() if k.startswith(("k_bbox", "k_make_grid", "k_bucket"))),
+       "note": "one launch = both directions of the 1M-vs-1M Chamfer step; calibrated FETCH_SIZE + WRITE_SIZE, see the header of the source file"}
+if dom:
+    c = {k: mean(v) for k, v in sq[dom[0]].items()}
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0)
+    if cyc and c.get("SQ_INSTS_VALU"):
+        # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, wave scheduling); one scalar
+        # instruction per cycle per CU
+        rep["valu_issue_frac"] = 2.0 * c["SQ_INSTS_VALU"] / (N_SIMD * cyc)
+        rep["salu_issue_frac"] = c.get("SQ_INSTS_SALU", 0.0) / (N_CU * cyc)
+        rep["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c.get("SQ_WAVES", 1.0)
+        rep["salu_insts_per_wave"] = c.get("SQ_INSTS_SALU", 0.0) / c.get("SQ_WAVES", 1.0)
+    if c.get("SQ_ACTIVE_INST_VALU"):
+        rep["active_lane_frac"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        rep["valu_active_quadcycles_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc) if cyc else None
+    if c.get("SQ_INST_CYCLES_SALU") and cyc:
+        rep["salu_busy_frac"] = c["SQ_INST_CYCLES_SALU"] / (N_CU * cyc)
+json.dump(rep, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+print(line[:600]); print("\n".join(cal)); print("\n".join(out[4:14])); print(json.dumps(rep, indent=1))

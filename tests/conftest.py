@@ -13,19 +13,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _gpu_available():
-    try:
-        from point_cloud_utils_amd import _lib
-        return _lib.device_count() > 0
-    except Exception:
-        return False
-
-
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly rather than skip: the product has no CPU fallback.
-    pass
-
-
 @pytest.fixture(scope="session")
 def oracle_kind():
     import oracle
@@ -40,6 +27,18 @@ def cloud(seed, n, dtype, scale=1.0, offset=0.0):
     if scale != 1.0 or offset != 0.0:
         a = (a * dtype(scale) + dtype(offset)).astype(dtype)
     return a
+
+
+def mesh_samples(v, f, n, seed=5):
+    """BASELINE config 5: n area-weighted uniform samples on the triangles (v, f) -- face ~ areas, barycentric
+    (1 - sqrt(u), sqrt(u) (1 - w), sqrt(u) w) -- in float64, C-contiguous."""
+    rng = np.random.default_rng(seed)
+    tri = v[f]
+    areas = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    fi = rng.choice(len(f), n, p=areas / areas.sum())
+    u = rng.random(n); w = rng.random(n); su = np.sqrt(u)
+    s = (1 - su)[:, None] * tri[fi, 0] + (su * (1 - w))[:, None] * tri[fi, 1] + (su * w)[:, None] * tri[fi, 2]
+    return np.ascontiguousarray(s)
 
 
 def read_ply_vertices(path):

@@ -1,0 +1,151 @@
+"""GPU parity tests (-m gpu) at the FULL sizes of BASELINE.json's configs, against the reference's own nanoflann
+(oracle kind "ref" where oracle/_ref was built, the pinned C restatement otherwise), through the public API = the C ABI:
+
+  headline  chamfer_distance 1M-vs-1M f32: value within 1e-4, both correspondence arrays bit-exact
+  C2        k_nearest_neighbors k=1, 1M-vs-1M f32: indices + distance bits
+  C3        k_nearest_neighbors k=16, 4M-vs-4M f32: indices + distance bits (incl. the ~40 exact ties -> kd-tree order)
+  C4        hausdorff_distance on full-size 262,144-point pairs through the batch entry point
+  C5        chamfer_distance f64, bunny (2,885 vertices) vs 1M area-weighted mesh samples: both index arrays exact
+plus k > 127 (the reference accepts any k > 0) and the batch entry points against the single-pair calls."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import cloud, mesh_samples
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pcu():
+    import point_cloud_utils_amd as m
+    from point_cloud_utils_amd import _lib
+    assert _lib.device_count() > 0, "no GPU visible: the gfx950 path has no CPU fallback"
+    return m
+
+
+def test_headline_chamfer_1m_vs_reference(pcu, oracle_kind):
+    n = 1_000_000
+    x, y = cloud(1000, n, np.float32), cloud(1001, n, np.float32)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=oracle_kind)
+    ch = pcu.chamfer_distance(x, y)                                   # the benchmarked call shape (fused epilogue, no rows)
+    assert type(ch) == np.float32
+    assert abs(float(ch) - float(ch0)) <= 1e-4 * float(ch0)
+    ch2, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)      # row-based path: correspondences
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch2) - float(ch0)) <= 1e-4 * float(ch0)
+    assert float(ch) == float(pcu.chamfer_distance(x, y))             # reproducible run to run (exact accumulation of the stragglers)
+    # device-resident inputs (what bench.py times) give the same value
+    import torch
+    tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    assert float(pcu.chamfer_distance(tx, ty)) == float(ch)
+    # Hausdorff on the same pair (fused arg-max) against the reference
+    assert pcu.hausdorff_distance(x, y, return_index=True) == oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind)
+    assert pcu.one_sided_hausdorff_distance(x, y) == oracle.one_sided_hausdorff_distance(x, y, kind=oracle_kind)
+
+
+def test_config2_knn_k1_1m(pcu, oracle_kind):
+    n = 1_000_000
+    q, r = cloud(1000, n, np.float32), cloud(1001, n, np.float32)
+    d, c = pcu.k_nearest_neighbors(q, r, 1)
+    d0, c0 = oracle.k_nearest_neighbors(q, r, 1, kind=oracle_kind)
+    assert np.array_equal(c, c0), pcu.last_stats()
+    assert np.array_equal(d.view(np.uint32), d0.view(np.uint32))
+
+
+def test_config3_knn_k16_4m(pcu, oracle_kind):
+    n = 4_000_000
+    q, r = cloud(1000, n, np.float32), cloud(1001, n, np.float32)
+    d, c = pcu.k_nearest_neighbors(q, r, 16)
+    st = pcu.last_stats()
+    d0, c0 = oracle.k_nearest_neighbors(q, r, 16, kind=oracle_kind)
+    assert np.array_equal(c, c0), (int((c != c0).any(1).sum()), st)
+    assert np.array_equal(d.view(np.uint32), d0.view(np.uint32))
+    assert st["n_tie_true"] > 0, st          # the exact ties of this config went through the kd-tree order
+
+
+def test_config4_hausdorff_full_size_pairs(pcu, oracle_kind):
+    from point_cloud_utils_amd import batched
+    n, npairs = 262144, 6
+
+    def get_pair(p):
+        return cloud(1000 + 2 * p, n, np.float32), cloud(1001 + 2 * p, n, np.float32)
+
+    hd = batched.batched_hausdorff(get_pair, npairs)
+    for p in range(npairs):
+        x, y = get_pair(p)
+        assert tuple(hd[p]) == pcu.hausdorff_distance(x, y, return_index=True)          # batch entry point == single-pair call
+        if p < 3:
+            assert tuple(hd[p]) == oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind)
+    # device-resident pairs (the benchmarked mode)
+    import torch
+    pairs = [tuple(torch.from_numpy(a).cuda() for a in get_pair(p)) for p in range(npairs)]
+    hd2 = batched.batched_hausdorff(lambda p: pairs[p], npairs, workers=3)
+    assert np.array_equal(hd, hd2)
+    ch = batched.batched_chamfer(lambda p: pairs[p], npairs)
+    for p in range(2):
+        x, y = get_pair(p)
+        assert ch[p] == float(pcu.chamfer_distance(x, y))
+        assert abs(ch[p] - float(oracle.chamfer_distance(x, y, kind=oracle_kind))) <= 1e-4 * ch[p]
+
+
+def test_config5_bunny_vs_mesh_samples_f64(pcu, oracle_kind):
+    bunny = np.load(os.path.join(GOLD, "bunny_v.npy")).astype(np.float64)
+    f = np.load(os.path.join(GOLD, "bunny_f.npy"))
+    s = mesh_samples(bunny, f, 1_000_000, seed=5)
+    ch, cxy, cyx = pcu.chamfer_distance(bunny, s, return_index=True)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(bunny, s, return_index=True, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch) - float(ch0)) <= 1e-6 * float(ch0)
+    assert abs(float(pcu.chamfer_distance(bunny, s)) - float(ch0)) <= 1e-6 * float(ch0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_k_beyond_the_grid_search(pcu, oracle_kind, dtype):
+    """k > 127: the reference answers any k > 0 (src/point_cloud_distance.cpp:133-135), so does the GPU path (the reference's
+    kd-tree traversal with a k-slot result set): indices and distance bits equal, -1 padding when k > m, ties included."""
+    for n, m, k in ((3000, 5000, 128), (2000, 40000, 200), (300, 900, 1000), (50, 20000, 9000)):
+        q, r = cloud(41, n, dtype), cloud(42, m, dtype)
+        d, c = pcu.k_nearest_neighbors(q, r, k)
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+        assert np.array_equal(c, c0), (n, m, k)
+        assert np.array_equal(d, d0), (n, m, k)
+    base = cloud(43, 1500, dtype)
+    r = np.concatenate([base, base])                                   # every distance tied: the kd-tree order decides
+    d, c = pcu.k_nearest_neighbors(base[:400], r, 300, squared_distances=True)
+    d0, c0 = oracle.k_nearest_neighbors(base[:400], r, 300, squared_distances=True, kind=oracle_kind)
+    assert np.array_equal(c, c0) and np.array_equal(d, d0)
+    with pcu.DatasetIndex(r) as index:
+        d, c = index.k_nearest_neighbors(base[:100], 130)
+        d0, c0 = oracle.k_nearest_neighbors(base[:100], r, 130, kind=oracle_kind)
+        assert np.array_equal(c, c0) and np.array_equal(d, d0)
+
+
+def test_fused_calls_fall_back_when_rows_are_needed(pcu, oracle_kind):
+    """The fused epilogues (no result rows) must give way to the row-based path whenever they cannot stand: far-apart
+    clouds (queries uncertified after radius 2), unbalanced dataset grids (refit), Hausdorff arg-max rows with tied
+    neighbours. Same results as the reference either way."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    cases = {
+        "far": (cloud(1, n, np.float32, scale=0.2), cloud(2, n, np.float32, scale=0.2, offset=3.0)),
+        "cluster": (np.concatenate([rng.random((n, 3)), rng.normal(0.5, 0.001, (n, 3))]).astype(np.float32), cloud(3, n, np.float32)),
+        "dups": (np.repeat(cloud(4, n // 4, np.float32), 4, axis=0), cloud(5, n, np.float32)),
+    }
+    for name, (x, y) in cases.items():
+        for a, b in ((x, y), (y, x)):
+            assert pcu.hausdorff_distance(a, b, return_index=True) == oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind), name
+            assert pcu.one_sided_hausdorff_distance(a, b) == oracle.one_sided_hausdorff_distance(a, b, kind=oracle_kind), name
+            ch, ch0 = pcu.chamfer_distance(a, b), oracle.chamfer_distance(a, b, kind=oracle_kind)
+            assert abs(float(ch) - float(ch0)) <= 1e-4 * float(ch0), name
+
+
+def test_squeeze_of_singleton_shapes(pcu):
+    q, r = cloud(1, 1, np.float32), cloud(2, 50, np.float32)
+    d, c = pcu.k_nearest_neighbors(q, r, 1)
+    assert d.shape == () and c.shape == () and c.dtype == np.int64
+    d, c = pcu.k_nearest_neighbors(q, r, 3)
+    assert d.shape == (3,) and c.shape == (3,)

@@ -292,11 +292,6 @@ def test_metrics_under_exact_ties(pcu, oracle_kind, dtype):
         assert abs(float(v) - float(v0)) <= tol * float(v0), p
 
 
-def test_k_limit_is_a_clear_error(pcu):
-    with pytest.raises(ValueError, match="k = 128 > 127"):
-        pcu.k_nearest_neighbors(cloud(1, 100, np.float32), cloud(2, 300, np.float32), 128)
-
-
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_unbalanced_clouds_refit_path(pcu, oracle_kind, dtype):
     """A far outlier inflating the bbox and a tight cluster: the first grid is badly unbalanced, the passes give up,
