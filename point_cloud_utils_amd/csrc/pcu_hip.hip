@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -413,13 +414,11 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     return 0;
 }
 template <typename T>
-static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr, const FuseTail<T>* tail = nullptr) {
+static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
     const int blocks = a.qcount_dev ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
-    FuseTail<T> ft; memset(&ft, 0, sizeof ft);
-    if (tail) ft = *tail;
-#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, ft); break;
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, blocks); break;
     switch (K) {
         PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64) PCU_CASE(128)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
@@ -466,6 +465,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     // fused epilogue (reduce.h): per-block partials of the k = 1 lane pass instead of result rows
     int fuse = FUSE_NONE; int n_flat = 0;
     double* f_sum = nullptr; T* f_max_v = nullptr; long long* f_max_k = nullptr;
+    unsigned long long* f_limbs = nullptr; double* f_special = nullptr; T* f_wave_v = nullptr; long long* f_wave_k = nullptr;
 };
 
 template <typename T>
@@ -479,6 +479,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
+    a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k;
     return a;
 }
 
@@ -486,8 +487,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
 // device-side lists: possible ties (radius 1, total order) and stragglers (radius 2). What is still uncertified after
 // that (list u2; next to nothing on balanced clouds) is finished by search_finish's host-driven loop.
 template <typename T>
-static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true,
-                          const FuseTail<T>* tail = nullptr) {
+static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true) {
     const SearchScratch<T>& sc = j.sc;
     const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
     if (zero_counters) HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
@@ -518,10 +518,10 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
         b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
-        if (launch_search_wave<T>(KL, b, s, nullptr, tail)) return -1;
+        if (launch_search_wave<T>(KL, b, s)) return -1;
         if (st) st->n_passes += 2 + j.n_fine;
     } else {
-        if (tail) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
+        if (j.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
         if (j.skew_check) b.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
@@ -541,10 +541,9 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 template <typename T>
 static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_gather_kernels() && use_k1_kernel(); }
 template <typename T>
-static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st,
-                               const FuseTail<T>* tail = nullptr) {
+static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st) {
     if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
-        if (tail) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue without the paired k = 1 pass");
+        if (j0.fuse || j1.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue without the paired k = 1 pass");
         if (search_enqueue(c, s, j0, st, /*zero_counters=*/false)) return -1;
         return search_enqueue(c, s, j1, st, false);
     }
@@ -567,7 +566,7 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
     if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
     if (launch_search_fast<T>(1, a[0], j0.qidx.n, s, true, &a[1], j1.qidx.n)) return -1;
     if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
-    if (launch_search_wave<T>(2, b[0], s, &b[1], tail)) return -1;
+    if (launch_search_wave<T>(2, b[0], s, &b[1])) return -1;
     if (st) st->n_passes += 4;
     return 0;
 }
@@ -1067,17 +1066,22 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
                6 * align_up((size_t)kRedBlocks * 8, 256) + 8192 +
                3 * (align_up((size_t)grid8((int)nx, kBlock) * 8, 256) + align_up((size_t)grid8((int)ny, kBlock) * 8, 256)) +
-               2 * align_up((size_t)2 * kWaveBlocks * 8, 256) + align_up(sizeof(CallBlock), 256) + 1024;
+               4 * align_up((size_t)kWaveBlocks * (kBlock / 64) * 8, 256) + align_up(sizeof(CallBlock), 256) + 1024;
     if (!on_dev) b += align_up((size_t)nx * 3 * sizeof(T), 256) + align_up((size_t)ny * 3 * sizeof(T), 256) +
                       align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256);
     return b;
 }
 template <typename T>
 static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, hipStream_t s2, PairState<T>& P, pcu_hip_stats* st) {
-    const FuseTail<T>* tail = P.fuse ? &P.tail : nullptr;
-    if (P.two && s2 == s) return search_enqueue_pair(c, s, P.xy, P.yx, st, tail);
-    if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false, P.two ? nullptr : tail)) return -1;
-    if (P.two && search_enqueue(c, s2, P.yx, st, false)) return -1;
+    if (P.two && s2 == s) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
+    else {
+        if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
+        if (P.two && search_enqueue(c, s2, P.yx, st, false)) return -1;
+    }
+    if (P.fuse) {               // the launch that ends a fused call (reduce.h)
+        hipLaunchKernelGGL(k_fuse_tail<T>, dim3(1), dim3(kTailThreads), 0, s, P.tail);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 template <typename T>
@@ -1110,18 +1114,19 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (fuse_mode != FUSE_NONE && !no_fuse && s2 == s && lane_k1_job(P.xy) && (!two_sided || lane_k1_job(P.yx))) {
         P.fuse = fuse_mode;
         FuseTail<T>& t = P.tail; memset(&t, 0, sizeof t);
-        t.mode = fuse_mode;
-        for (int d = 0; d < (two_sided ? 2 : 1); ++d) {
+        t.mode = fuse_mode; t.njobs = two_sided ? 2 : 1; t.nwaves = kWaveBlocks * (kBlock / 64);
+        for (int d = 0; d < t.njobs; ++d) {
             SearchJob<T>& J = d ? P.yx : P.xy;
             J.fuse = fuse_mode; J.n_flat = grid8(J.qidx.n, kBlock);
             if (aalloc(ar, &J.f_sum, (size_t)J.n_flat) || aalloc(ar, &J.f_max_v, (size_t)J.n_flat) || aalloc(ar, &J.f_max_k, (size_t)J.n_flat)) return -1;
+            if (aalloc(ar, &J.f_wave_v, (size_t)t.nwaves) || aalloc(ar, &J.f_wave_k, (size_t)t.nwaves)) return -1;
+            J.f_limbs = &P.cb->limbs[d][0]; J.f_special = &P.cb->special[d];
             t.flat_sum[d] = J.f_sum; t.flat_v[d] = J.f_max_v; t.flat_k[d] = J.f_max_k; t.nflat[d] = J.n_flat;
+            t.wave_v[d] = J.f_wave_v; t.wave_k[d] = J.f_wave_k; t.limbs[d] = J.f_limbs; t.special[d] = J.f_special;
         }
-        if (aalloc(ar, &t.wv, (size_t)2 * kWaveBlocks) || aalloc(ar, &t.wk, (size_t)2 * kWaveBlocks)) return -1;
-        t.limbs = &P.cb->limbs[0][0]; t.special = P.cb->special;
-        t.ticket = reinterpret_cast<unsigned*>(P.rb->pad);
-        t.out_sums = P.rb->sums; t.out_v = P.res_v; t.out_ij = P.rb->ij; t.out_tie = P.rb->pad + 2;
         t.result_block = reinterpret_cast<const int*>(P.rb); t.host_block = c->h_pinned; t.seq = ++c->seq;
+        t.w_sums = (int)(offsetof(ResultBlock, sums) / 4); t.w_vals = (int)(offsetof(ResultBlock, vals) / 4);
+        t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;
     }
     tm.mark(0);
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, 
 // The wave-per-query pass takes its queries from device-side lists whose ORDER depends on the timing of atomics, so its
 // share of a floating-point sum would not be reproducible run to run. It is therefore accumulated EXACTLY: every value is
 // split into 32-bit limbs of a wide fixed-point number (bit 0 = 2^-1074) and each limb is added with an integer atomic into
-// its own 64-bit word (2^32 additions cannot overflow a word; carries are propagated once, by the fold). Integer addition
-// commutes, so the result does not depend on the order, and the fold's conversion back to double is deterministic.
+// its own 64-bit word (2^32 additions cannot overflow a word). Integer addition commutes, so the limbs do not depend on the
+// order, and the fold's conversion back to double (exact_term / exact_total) is a fixed sequence of operations on them.
 constexpr int kAccLimbs = 66;              // (2045 + 53 + 32) / 32 + 1: any finite double fits
 __device__ __forceinline__ void exact_add(unsigned long long* limbs, double* special, double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -108,36 +108,96 @@ __device__ __forceinline__ void exact_add(unsigned long long* limbs, double* spe
     if (w1) atomicAdd(&limbs[L + 1], w1);
     if (w2) atomicAdd(&limbs[L + 2], w2);
 }
-// One thread: the accumulated value as a double (carries propagated in place, then summed from the top limb down).
-__device__ __noinline__ double exact_value(unsigned long long* limbs, const double* special) {
-    unsigned long long carry = 0;
-#pragma unroll 1
-    for (int i = 0; i < kAccLimbs; ++i) {
-        const unsigned long long v = __hip_atomic_load(&limbs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + carry;
-        __hip_atomic_store(&limbs[i], v & 0xffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        carry = v >> 32;
-    }
-    double r = 0;
-#pragma unroll 1
-    for (int i = kAccLimbs - 1; i >= 0; --i) {
-        const unsigned long long v = __hip_atomic_load(&limbs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v) r += ldexp((double)v, 32 * i - 1074);
-    }
-    return r + __hip_atomic_load(special, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The accumulated value as a double: term l = limb l scaled to its weight (thread l of the folding block), the terms summed by
+// block_sum's fixed tree. A limb holds up to 2^32 additions of 32-bit values, so its conversion to double may round (2^-53
+// relative): the result is deterministic -- which is the point -- and accurate far beyond the fp64 sums it is added to.
+__device__ __forceinline__ double exact_term(const unsigned long long* limbs, const double* special, int l) {
+    if (l >= kAccLimbs) return __hip_atomic_load(special, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load(&limbs[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v ? ldexp((double)v, 32 * l - 1074) : 0.0;
 }
-
 enum { FUSE_NONE = 0, FUSE_SUM = 1, FUSE_ARGMAX = 2 };
-// What the wave-per-query launch of a fused call needs to finish the call (by value, in its kernel arguments).
+constexpr int kTailThreads = 1024;
+// Arguments of k_fuse_tail, the one-block launch that ends a fused call.
 template <typename T>
 struct FuseTail {
     int mode;                                    // FUSE_*
+    int njobs;                                   // directions
     const double* flat_sum[2]; const T* flat_v[2]; const long long* flat_k[2]; int nflat[2];   // the lane pass's per-block partials, per direction
-    double* wsum; T* wv; long long* wk;          // this launch's per-block partials, [direction][gridDim.x] (FUSE_ARGMAX)
-    unsigned long long* limbs; double* special;  // [direction][kAccLimbs], [direction]: exact sum of this launch's distances (FUSE_SUM)
-    unsigned* ticket;
-    double* out_sums; T* out_v; long long* out_ij; int* out_tie;      // fields of the call's result block
+    const T* wave_v[2]; const long long* wave_k[2]; int nwaves;                                // the wave pass's per-wave arg-max partials
+    unsigned long long* limbs[2]; double* special[2];                                          // the wave pass's exact sums
     const int* result_block; int* host_block; unsigned seq;
+    int w_sums, w_vals, w_ij, w_tie;             // word offsets of sums[2] / vals / ij[4] / tie[2] inside the result block
 };
+
+// ONE block folds a fused call: the lane pass's per-block partials (k_search1_flat), the wave pass's share (exact limbs or
+// per-wave arg-max partials), both directions; the results and the search counters of the call's result block go to pinned
+// host memory, sequence word last (the host spins on it, see k_pnorm_pair). Every thread requests all its inputs before the
+// first reduction -- the launch is a chain of memory round trips, not work -- and all sums run in a fixed order (thread-strided
+// partial sums, then a fixed tree), so the value is reproducible run to run.
+__device__ __forceinline__ double tail_sum(double v, double* s_buf) {      // fixed tree over the block; valid in every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = s_buf[0];
+    for (int w = 1; w < kTailThreads / 64; ++w) r += s_buf[w];
+    return r;
+}
+struct VK { double v; long long k; };           // (value widened to double: exact for float, identity for double)
+__device__ __forceinline__ VK comb_max(VK a, VK b) { return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a; }
+__device__ __forceinline__ VK shfl_vk(VK a, int o) { VK r; r.v = __shfl_xor(a.v, o, 64); r.k = __shfl_xor(a.k, o, 64); return r; }
+
+template <typename T>
+__global__ __launch_bounds__(kTailThreads) void k_fuse_tail(const FuseTail<T> ft) {
+    __shared__ double s_d[kTailThreads / 64]; __shared__ double s_mv[kTailThreads / 64]; __shared__ long long s_mk[kTailThreads / 64];
+    __shared__ int s_res[64]; __shared__ unsigned long long s_mask;
+    const int tid = threadIdx.x;
+    double acc[2] = {0, 0}, term[2] = {0, 0};
+    VK best[2] = {{-DBL_MAX, 0x7fffffffffffffffll}, {-DBL_MAX, 0x7fffffffffffffffll}};
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {           // (constant trip count + unroll: the per-direction values stay in registers)
+        if (jb >= ft.njobs) continue;
+        if (ft.mode == FUSE_SUM) {
+            for (int i = tid; i < ft.nflat[jb]; i += kTailThreads) acc[jb] += ft.flat_sum[jb][i];
+            if (tid <= kAccLimbs) term[jb] = exact_term(ft.limbs[jb], ft.special[jb], tid);
+        } else {
+            for (int i = tid; i < ft.nflat[jb]; i += kTailThreads) { const VK c = {(double)ft.flat_v[jb][i], ft.flat_k[jb][i]}; best[jb] = comb_max(best[jb], c); }
+            for (int i = tid; i < ft.nwaves; i += kTailThreads) { const VK c = {(double)ft.wave_v[jb][i], ft.wave_k[jb][i]}; best[jb] = comb_max(best[jb], c); }
+        }
+    }
+    const int rbw = tid < 63 ? ft.result_block[tid] : 0;
+    if (tid == 0) s_mask = 0ull;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        if (jb >= ft.njobs) continue;
+        if (ft.mode == FUSE_SUM) {
+            const double r = tail_sum(acc[jb] + term[jb], s_d);
+            if (tid == 0) { *reinterpret_cast<double*>(&s_res[ft.w_sums + 2 * jb]) = r; s_mask |= 3ull << (ft.w_sums + 2 * jb); }
+        } else {
+            VK v = best[jb];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = comb_max(v, shfl_vk(v, o));
+            __syncthreads();
+            if ((tid & 63) == 0) { s_mv[tid >> 6] = v.v; s_mk[tid >> 6] = v.k; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < kTailThreads / 64; ++w) { const VK c = {s_mv[w], s_mk[w]}; v = comb_max(v, c); }
+                const int wv = ft.w_vals + jb * (int)(sizeof(T) / 4), wi = ft.w_ij + 4 * jb, wt = ft.w_tie + jb;
+                *reinterpret_cast<T*>(&s_res[wv]) = (T)v.v; s_mask |= (sizeof(T) == 8 ? 3ull : 1ull) << wv;
+                *reinterpret_cast<long long*>(&s_res[wi]) = v.k >> 32; *reinterpret_cast<long long*>(&s_res[wi + 2]) = v.k & 0x7fffffffll; s_mask |= 15ull << wi;
+                s_res[wt] = (int)((v.k >> 31) & 1ll); s_mask |= 1ull << wt;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        if (tid < 63) ft.host_block[tid] = ((s_mask >> tid) & 1ull) ? s_res[tid] : rbw;
+        __threadfence_system();
+        if (tid == 63) __hip_atomic_store(&ft.host_block[63], (int)ft.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // Hausdorff, row-based path: is the arg-max source row (ij[0], in the call's result block) one of the direction's queries
 // with a genuine tie? Only then does the returned j depend on the reference's tie order (pcu_hip.hip, hausdorff_end).

@@ -61,6 +61,9 @@ struct SearchArgs {
     // (key = source row << 32 | tie bit 31 | dataset row). No rows are written and only deferred lanes enter the tie list.
     int fuse;
     double* f_sum; T* f_max_v; long long* f_max_k;
+    // ... and the wave-per-query pass adds its few queries: FUSE_SUM exactly, into f_limbs / f_special (reduce.h: exact_add);
+    // FUSE_ARGMAX one partial per wave in f_wave_v / f_wave_k[wave]. k_fuse_tail (reduce.h) folds everything.
+    unsigned long long* f_limbs; double* f_special; T* f_wave_v; long long* f_wave_k;
 };
 
 // Append `value` for lanes with `flag` set; one atomic per wave.
@@ -382,12 +385,12 @@ template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { retur
 // (EARLY = false: one more dependent wait per wave, but their 32 registers are not live during the centre scan: 68 VGPRs
 // instead of 93, 7 waves per SIMD instead of 5). EARLY = true fetches them right away (79 VGPRs; measured equal).
 template <typename T, bool EARLY, int FUSE>
-__device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int bid, const int nblk, bool& f_ok, T& f_v, long long& f_key) {
+__device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int nq_arg, const int bid, const int nblk, bool& f_ok, T& f_v, long long& f_key) {
     __shared__ uint2 s_rng[8][kBlock];
     const int per = nblk >> 3;
     const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search (nblk and the side's first block: multiples of 8)
     const int t = vb * kBlock + threadIdx.x;
-    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    const int nq = a.qcount_dev ? *a.qcount_dev : nq_arg;
     if (t >= nq) return;
     const int tid = threadIdx.x;
     const int qpos = a.qlist ? a.qlist[t] : t;
@@ -566,7 +569,10 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
     const int side = (int)blockIdx.x >= nb0 ? 1 : 0;
     const int bid = side ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
     bool ok = false; T v = (T)0; long long key = 0x7fffffffffffffffll;
-    search1_flat_body<T, EARLY, FUSE>(p.a[side], bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
+    // (nq is picked by a scalar select: read through p.a[side] the compiler parks both sides' values in SCRATCH to index them --
+    // 8 bytes of private memory written per lane, 16 MB of HBM writes per 1M-vs-1M launch, profiles/r02a_pmc.txt)
+    const int nq_side = side ? p.a[1].nq : p.a[0].nq;
+    search1_flat_body<T, EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
     if (FUSE == FUSE_SUM) {                     // one fp64 partial per block; lanes in a fixed order: reproducible
         const double r = block_sum(ok ? (double)v : 0.0);
         if (threadIdx.x == 0) p.a[side].f_sum[bid] = r;
@@ -717,22 +723,30 @@ template <typename T>
 __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d < d2 || (d == d2 && id < id2); }
 
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const FuseTail<T> ft) {
+__global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const int n_blocks) {
     const int lane = threadIdx.x & 63;
-    T fbest_v[2] = {-Limits<T>::max_v, -Limits<T>::max_v};                         // fused arg-max: this wave's best per direction
-    long long fbest_k[2] = {0x7fffffffffffffffll, 0x7fffffffffffffffll};
+    // fused arg-max: this wave's best per direction (named scalars: an array indexed by the direction is promoted to LDS, and
+    // addressing it needs the block dimensions, i.e. a fetch of the dispatch packet in the prologue)
+    T fbv0 = -Limits<T>::max_v, fbv1 = -Limits<T>::max_v;
+    long long fbk0 = 0x7fffffffffffffffll, fbk1 = 0x7fffffffffffffffll;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * kBlock) >> 6;
-    // work items: job 0's list(s), then (two-sided calls) job 1's
-    int total0 = (a0.qcount_dev ? *a0.qcount_dev : a0.nq) + (a0.qlist2 ? *a0.qcount2_dev : 0);
-    int total1 = njobs > 1 ? (a1.qcount_dev ? *a1.qcount_dev : a1.nq) + (a1.qlist2 ? *a1.qcount2_dev : 0) : 0;
-    if (a0.skew_limit > 0.f && (float)a0.gp->sumsq > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
-    if (njobs > 1 && a1.skew_limit > 0.f && (float)a1.gp->sumsq > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
+    const int nwaves = (n_blocks * kBlock) >> 6;       // (n_blocks = gridDim.x, as an argument: reading gridDim costs a fetch of the dispatch packet)
+    // work items: job 0's list(s), then (two-sided calls) job 1's. This launch usually serves a few hundred queries, so its
+    // time is its chain of dependent memory round trips; the six device words its prologue needs are therefore fetched
+    // unconditionally and together (absent lists point at a valid dummy word) instead of one pointer test + load + wait each.
+    const int* const c00 = a0.qcount_dev ? a0.qcount_dev : a0.skew_flag; const int* const c01 = a0.qlist2 ? a0.qcount2_dev : a0.skew_flag;
+    const int* const c10 = a1.qcount_dev ? a1.qcount_dev : a1.skew_flag; const int* const c11 = a1.qlist2 ? a1.qcount2_dev : a1.skew_flag;
+    const int v00 = *c00, v01 = *c01, v10 = *c10, v11 = *c11;
+    const unsigned long long ss0 = a0.gp->sumsq, ss1 = a1.gp->sumsq;
+    int total0 = (a0.qcount_dev ? v00 : a0.nq) + (a0.qlist2 ? v01 : 0);
+    int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
+    if (a0.skew_limit > 0.f && (float)ss0 > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
+    if (njobs > 1 && a1.skew_limit > 0.f && (float)ss1 > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
         const bool job1 = wg >= total0;
         const SearchArgs<T>& a = job1 ? a1 : a0;
         const int w = job1 ? wg - total0 : wg;
-        const int nq1 = a.qcount_dev ? *a.qcount_dev : a.nq;
+        const int nq1 = a.qcount_dev ? (job1 ? v10 : v00) : a.nq;
         const GridParams<T>& g = *a.gp;
         const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
         const int kreq = a.kreq;
@@ -828,8 +842,11 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             // fused epilogue (k = 1): the query's distance joins the direction's exact sum / this wave's arg-max; no row, no tie list
             const T v0 = (T)__shfl(a.squared ? my_d : sqrt(my_d), 0, 64);
             const int i0 = __shfl(my_i, 0, 64);
-            if (a.fuse == FUSE_SUM) { if (lane == 0) exact_add(ft.limbs + (job1 ? kAccLimbs : 0), ft.special + (job1 ? 1 : 0), (double)v0); }
-            else argmax_combine(fbest_v[job1 ? 1 : 0], fbest_k[job1 ? 1 : 0], v0, ((long long)q.idx << 32) | (long long)((unsigned)i0 | (tie ? 0x80000000u : 0u)));
+            if (a.fuse == FUSE_SUM) { if (lane == 0) exact_add(a.f_limbs, a.f_special, (double)v0); }
+            else {
+                const long long key = ((long long)q.idx << 32) | (long long)((unsigned)i0 | (tie ? 0x80000000u : 0u));
+                if (job1) argmax_combine(fbv1, fbk1, v0, key); else argmax_combine(fbv0, fbk0, v0, key);
+            }
         } else if (certified) {
             if (lane < kreq) {
                 const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)kreq + lane;
@@ -848,56 +865,10 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             a.unresolved[atomicAdd(a.n_unresolved, 1)] = qpos;
         }
     }
-    if (ft.mode == FUSE_NONE) return;
-    // ---- fused epilogue: this launch ends the call. Per-block partials (arg-max) / exact limbs (sum) are complete when a block
-    // takes its ticket; the block that takes the last one folds them with the lane pass's per-block partials (written by the
-    // previous launch), fills the result block and hands it to the host (sequence word last, see k_pnorm_pair).
-    __shared__ T s_fv[2][kBlock / 64]; __shared__ long long s_fk[2][kBlock / 64];
-    __shared__ bool s_last;
-    const int wv_in_blk = threadIdx.x >> 6;
-    if (ft.mode == FUSE_ARGMAX && lane == 0) {
-        s_fv[0][wv_in_blk] = fbest_v[0]; s_fk[0][wv_in_blk] = fbest_k[0];
-        s_fv[1][wv_in_blk] = fbest_v[1]; s_fk[1][wv_in_blk] = fbest_k[1];
-    }
-    wait_stores();                               // this wave's limb atomics have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (ft.mode == FUSE_ARGMAX) {
-            for (int jb = 0; jb < njobs; ++jb) {
-                T v = s_fv[jb][0]; long long kk = s_fk[jb][0];
-                for (int w = 1; w < kBlock / 64; ++w) argmax_combine(v, kk, s_fv[jb][w], s_fk[jb][w]);
-                publish(&ft.wv[jb * (int)gridDim.x + (int)blockIdx.x], v); publish(&ft.wk[jb * (int)gridDim.x + (int)blockIdx.x], kk);
-            }
-            wait_stores();
-        }
-        s_last = take_ticket(ft.ticket, gridDim.x);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    for (int jb = 0; jb < njobs; ++jb) {
-        if (ft.mode == FUSE_SUM) {
-            double acc = 0;
-            for (int i = threadIdx.x; i < ft.nflat[jb]; i += kBlock) acc += ft.flat_sum[jb][i];
-            __syncthreads();                     // block_sum's shared array is reused
-            const double r = block_sum(acc);
-            if (threadIdx.x == 0) ft.out_sums[jb] = r + exact_value(ft.limbs + jb * kAccLimbs, ft.special + jb);
-        } else {
-            T v = -Limits<T>::max_v; long long kk = 0x7fffffffffffffffll;
-            for (int i = threadIdx.x; i < ft.nflat[jb]; i += kBlock) argmax_combine(v, kk, ft.flat_v[jb][i], ft.flat_k[jb][i]);
-            for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) argmax_combine(v, kk, peek(&ft.wv[jb * (int)gridDim.x + i]), peek(&ft.wk[jb * (int)gridDim.x + i]));
-            block_argmax(v, kk);
-            if (threadIdx.x == 0) {
-                ft.out_v[jb] = v; ft.out_ij[2 * jb] = kk >> 32; ft.out_ij[2 * jb + 1] = kk & 0x7fffffffll;
-                ft.out_tie[jb] = (int)((kk >> 31) & 1ll);
-            }
-        }
-    }
-    if (threadIdx.x == 0) { *ft.ticket = 0u; wait_stores(); }
-    __syncthreads();
-    if (ft.host_block && threadIdx.x < 64) {
-        if (threadIdx.x < 63) ft.host_block[threadIdx.x] = peek(&ft.result_block[threadIdx.x]);
-        __threadfence_system();
-        if (threadIdx.x == 63) __hip_atomic_store(&ft.host_block[63], (int)ft.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // fused arg-max: one partial per wave and direction (every wave writes its slots, so the fold needs no counts)
+    if (a0.fuse == FUSE_ARGMAX && lane == 0) {
+        a0.f_wave_v[wave] = fbv0; a0.f_wave_k[wave] = fbk0;
+        if (njobs > 1) { a1.f_wave_v[wave] = fbv1; a1.f_wave_k[wave] = fbk1; }
     }
 }
 
