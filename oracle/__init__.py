@@ -185,3 +185,60 @@ def chamfer_distance(x, y, return_index=False, p_norm=2, max_points_per_leaf=10,
     if return_index:
         return cham, cxy, cyx
     return cham
+
+
+# ---- normals: numpy restatement of src/point_cloud_normals.cpp:48-173 on top of a KNN checker ----------
+
+def _orient_filter(normals, dirs, drop_angle_threshold):
+    """:161-169: normal *= sign(normal . dir); drop if acos(normal . dir) > threshold. Returns (normals, keep)."""
+    d = np.einsum("ij,ij->i", normals, dirs)
+    normals = normals * np.sign(d)[:, None]
+    ang = np.arccos(np.clip(np.einsum("ij,ij->i", normals, dirs), -1.0, 1.0))
+    return normals, ~(ang > drop_angle_threshold)
+
+
+def normals_knn(points, num_neighbors, view_directions=None, drop_angle_threshold=np.pi / 2, max_points_per_leaf=10, kind="port"):
+    """estimate_local_normal_knn for every point (:115-173): neighbour offsets in the input dtype, widened to double, thin SVD,
+    V[:, 2]. Returns (idx, normals (float64, sign as numpy's SVD gives it), gap) where gap = (s1 - s2) / s0 of the kept points'
+    singular values (how well the smallest direction is separated: tests skip ill-conditioned fits)."""
+    p = _prep(points)
+    n = p.shape[0]
+    _, c = knn(p, p, num_neighbors, True, max_points_per_leaf, kind=kind)
+    ok = c[:, -1] >= 0
+    a = (p[np.where(c >= 0, c, 0)] - p[:, None, :]).astype(np.float64)          # (n, k, 3), differences taken in the input dtype
+    _, s, vt = np.linalg.svd(a, full_matrices=False)
+    normals = vt[:, 2, :] if vt.shape[1] >= 3 else np.zeros((n, 3))
+    gap = (s[:, 1] - s[:, 2]) / np.maximum(s[:, 0], 1e-300) if s.shape[1] >= 3 else np.zeros(n)
+    if view_directions is not None and len(view_directions):
+        normals, keep = _orient_filter(normals, np.asarray(view_directions, dtype=np.float64), drop_angle_threshold)
+        ok &= keep
+    idx = np.flatnonzero(ok)
+    return idx, normals[idx], gap[idx]
+
+
+def normals_ball(points, ball_radius, view_directions=None, drop_angle_threshold=np.pi / 2, min_pts_per_ball=3, weight_function="constant"):
+    """estimate_local_normal_rbf for every point (:48-113), brute force (small clouds only). Members: d2 < T(ball_radius) with
+    d2 = ((dx*dx)+(dy*dy))+(dz*dz) in the input dtype -- nanoflann's RadiusResultSet compares SQUARED distances (:278-283)."""
+    p = _prep(points)
+    n = p.shape[0]
+    rad = p.dtype.type(ball_radius)
+    normals = np.zeros((n, 3)); gap = np.zeros(n); ok = np.zeros(n, bool)
+    for i in range(n):
+        d = p[i] - p
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        m = np.flatnonzero(d2 < rad)
+        if len(m) < min_pts_per_ball:
+            continue
+        m = m[np.argsort(d2[m], kind="stable")]
+        w = np.ones(len(m))
+        if weight_function == "rbf":
+            r = np.sqrt(d2[m].astype(np.float64)) / ball_radius
+            w = (1.0 - r) ** 4 * (4 * r + 1.0)
+        a = (p[m] - p[i]).astype(np.float64) * w[:, None]
+        _, s, vt = np.linalg.svd(a, full_matrices=False)
+        normals[i] = vt[2]; gap[i] = (s[1] - s[2]) / max(s[0], 1e-300); ok[i] = True
+    if view_directions is not None and len(view_directions):
+        normals, keep = _orient_filter(normals, np.asarray(view_directions, dtype=np.float64), drop_angle_threshold)
+        ok &= keep
+    idx = np.flatnonzero(ok)
+    return idx, normals[idx], gap[idx]

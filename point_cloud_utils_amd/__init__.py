@@ -27,6 +27,7 @@ from . import _lib
 from ._lib import Stats, set_cell_occupancy, device_count  # noqa: F401
 
 __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_distance", "chamfer_distance",
+           "estimate_point_cloud_normals_knn", "estimate_point_cloud_normals_ball",
            "last_stats", "set_timing", "set_cell_occupancy", "device_count", "DatasetIndex"]
 
 _last_stats = [None]      # the Stats struct of the most recent call (turned into a dict on demand)
@@ -418,3 +419,6 @@ class DatasetIndex:
             self.close()
         except Exception:
             pass
+
+
+from ._normals import estimate_point_cloud_normals_knn, estimate_point_cloud_normals_ball  # noqa: E402,F401

@@ -83,6 +83,8 @@ def lib():
             getattr(L, "pcu_hip_index_knn_" + suf).argtypes = [vp, vp, vp, i64, ci, ci, vp, vp, u, vp, vp]
             getattr(L, "pcu_hip_hausdorff_batch_" + suf).argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, u, vp, vp]
             getattr(L, "pcu_hip_chamfer_batch_" + suf).argtypes = [vp, ci, vp, vp, vp, vp, ctypes.c_double, ci, vp, u, vp, vp]
+            getattr(L, "pcu_hip_normals_knn_" + suf).argtypes = [vp, vp, i64, vp, ci, ci, ctypes.c_double, vp, vp, u, vp, vp]
+            getattr(L, "pcu_hip_normals_ball_" + suf).argtypes = [vp, vp, i64, vp, ctypes.c_double, ci, ci, ci, ctypes.c_double, vp, vp, u, vp, vp]
         L.pcu_hip_ctx_set_batch_lanes.argtypes = [vp, ci]
         L.pcu_hip_index_size.restype = ctypes.c_int64
         L.pcu_hip_index_size.argtypes = [vp]

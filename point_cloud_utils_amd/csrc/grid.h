@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const BboxSide<T> a0, c
 // One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
 template <typename T>
-__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel) {
+__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel, double h_want = 0.0) {
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
@@ -170,7 +170,8 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
         bool act[3]; int nd = 0; double vol = 1.0;
         for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
         h = pow(vol / want, 1.0 / nd);
-        for (int it = 0; it < 200; ++it) {
+        if (h_want > 0 && h_want > h) h = h_want;             // fixed-radius searches (normals.h): cells no smaller than asked for
+        for (int it = 0; it < 400; ++it) {
             double cells = 1.0;
             for (int j = 0; j < 3; ++j) {
                 double g = act[j] ? floor(ext[j] / h) + 1.0 : 1.0;
@@ -195,11 +196,11 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
     gp->sumsq = 0ull; gp->closed = 0;
 }
 template <typename T>
-struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; };
+struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; double h_want; };
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_make_grid(const GridSide<T> a0, const GridSide<T> a1) {      // one block per side
     const GridSide<T>& a = blockIdx.x ? a1 : a0;
-    make_grid_body<T>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel);
+    make_grid_body<T>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel, a.h_want);
 }
 
 // Cell id + rank-in-cell of every point. The ranks come from a returning atomicAdd on the cell's counter, and those

@@ -21,6 +21,7 @@
 #include "reduce.h"
 #include "search.h"
 #include "kd_order.h"
+#include "normals.h"
 
 using namespace pcu;
 
@@ -62,6 +63,8 @@ struct pcu_hip_ctx {
     bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
+    char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
+                                              // sub-call's use of the arena
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;
     hipEvent_t batch_ev = nullptr;
 };
@@ -169,6 +172,7 @@ struct GridIndex {
     unsigned* pos_of = nullptr;           // row -> slot in `sorted` (only when asked for: k_unpermute)
     // bucketed build (grid.h): cells per bucket = 1 << shift; nb_max = host bound on the number of buckets
     bool bucketed = false; int shift = 0, nb_max = 0, n_zero = 0;
+    double h_want = 0.0;                  // > 0: cells at least this large (fixed-radius searches)
     Pt4<T>* tmp = nullptr; unsigned *bucket_total = nullptr, *bucket_start = nullptr, *block_base = nullptr, *large_list = nullptr, *n_large = nullptr;
 };
 
@@ -253,8 +257,8 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
         hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
-        const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n};
-        const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n} : g0;
+        const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n, a.h_want};
+        const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n, b->h_want} : g0;
         hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
     }
     // bucketed sides share their launches; a side too small / too coarse for buckets takes the atomic passes
@@ -1407,6 +1411,105 @@ static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int6
 }
 
 
+// ------------------------------------------------------------------------------------------------ normals
+static int aux_reserve(pcu_hip_ctx* c, size_t bytes) {
+    if (bytes > c->aux_cap) {
+        if (c->aux) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->aux)); c->aux = nullptr; c->aux_cap = 0; }
+        const size_t cap = align_up(bytes + (bytes >> 3), 1 << 20);
+        HIP_TRY(hipMalloc((void**)&c->aux, cap));
+        c->aux_cap = cap;
+    }
+    return 0;
+}
+static int validate_normals_input(int64_t n, int64_t n_dirs) {
+    if (n <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid point set with zero elements: points must have shape (n, 3), but got ot points.shape = (%lld, 3).", (long long)n);
+    if (n > 0x07fffff0ll) return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^27-16 rows are not supported");
+    if (n_dirs != 0 && n_dirs != n)
+        return fail(PCU_HIP_ERR_INVALID, "Invalid view directions does not match the number of points. If view directions are passed in, they must have the same "
+                    "shape as points. Got points.shape = (%lld, 3), and view_dirs.shape = (%lld, 3).", (long long)n, (long long)n_dirs);
+    return 0;
+}
+// estimate_point_cloud_normals_knn_internal (src/point_cloud_normals.cpp:375-411): self-KNN (the search of this library, so the
+// neighbour sets and their order are the reference's), then one plane fit per point (normals.h).
+template <typename T>
+static int normals_knn_impl(pcu_hip_ctx* c, const T* points, int64_t n, const T* dirs, int k, int max_leaf, double drop,
+                            T* out_n, uint8_t* out_keep, unsigned flags, void* stream, pcu_hip_stats* st) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (k <= 0) return fail(PCU_HIP_ERR_INVALID, "Invalid number of neighbors (%d) must be greater than 0.", k);
+    if (validate_normals_input(n, dirs ? n : 0)) return PCU_HIP_ERR_INVALID;
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
+    auto al = [](size_t v) { return align_up(v, 256); };
+    const size_t b_pts = al((size_t)n * 3 * sizeof(T));
+    const size_t need = (on_dev ? 0 : 2 * b_pts) + al((size_t)n * k * 8) + al((size_t)n * k * sizeof(T)) + (on_dev ? 0 : b_pts + al((size_t)n));
+    if (aux_reserve(c, need + 4096)) return PCU_HIP_ERR_RUNTIME;
+    char* p = c->aux;
+    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return r; };
+    const T* d_pts = points; const T* d_dirs = dirs;
+    if (!on_dev) {
+        T* t = (T*)take((size_t)n * 3 * sizeof(T)); HIP_TRY(hipMemcpyAsync(t, points, (size_t)n * 3 * sizeof(T), hipMemcpyHostToDevice, s)); d_pts = t;
+        if (dirs) { T* u = (T*)take((size_t)n * 3 * sizeof(T)); HIP_TRY(hipMemcpyAsync(u, dirs, (size_t)n * 3 * sizeof(T), hipMemcpyHostToDevice, s)); d_dirs = u; }
+    }
+    long long* d_nbr = (long long*)take((size_t)n * k * 8);
+    T* d_dist = (T*)take((size_t)n * k * sizeof(T));
+    T* d_out = out_n; uint8_t* d_keep = out_keep;
+    if (!on_dev) { d_out = (T*)take((size_t)n * 3 * sizeof(T)); d_keep = (uint8_t*)take((size_t)n); }
+    const unsigned kflags = (flags | PCU_HIP_PTRS_ON_DEVICE | PCU_HIP_SQUARED | PCU_HIP_STREAM_GIVEN) & ~(unsigned)(PCU_HIP_TIME_PHASES | PCU_HIP_TIME_KERNELS);
+    if (int rc = knn_impl<T>(c, d_pts, n, d_pts, n, k, max_leaf, d_dist, (int64_t*)d_nbr, kflags, (void*)s, st)) return rc;
+    const NormalsKnnArgs<T> a{d_pts, d_dirs, d_nbr, (int)n, k, drop, d_out, d_keep};
+    hipLaunchKernelGGL(k_normals_knn<T>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    if (!on_dev) {
+        HIP_TRY(hipMemcpyAsync(out_n, d_out, (size_t)n * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+// estimate_point_cloud_normals_ball_internal (:305-372): every point inside the ball (radiusSearch semantics of :75, see normals.h).
+template <typename T>
+static int normals_ball_impl(pcu_hip_ctx* c, const T* points, int64_t n, const T* dirs, double ball_radius, int min_pts, int max_pts,
+                             int weight_rbf, double drop, T* out_n, uint8_t* out_keep, unsigned flags, void* stream, pcu_hip_stats* st) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (!(ball_radius > 0.0)) return fail(PCU_HIP_ERR_INVALID, "Invalid radius (%f) must be greater than 0.", ball_radius);
+    if (min_pts < 3) return fail(PCU_HIP_ERR_INVALID, "Invalid min_pts_per_ball (%d) must be greater than 3.", min_pts);
+    if (max_pts > 0 && max_pts < 3) return fail(PCU_HIP_ERR_INVALID, "Invalid max_pts_per_ball (%d) must either be negative (no max) or a number greater than 3.", max_pts);
+    if (validate_normals_input(n, dirs ? n : 0)) return PCU_HIP_ERR_INVALID;
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
+    if (st) memset(st, 0, sizeof *st);
+    c->time_phases = false; c->time_kernels = false;
+    const double occ = 8.0;
+    size_t need = index_bytes<T>(n, occ) + 8192;
+    if (!on_dev) need += 3 * align_up((size_t)n * 3 * sizeof(T), 256) + align_up((size_t)n, 256);
+    if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T *d_pts, *d_dirs = dirs;
+        if ((rc = stage_in(ar, points, n, on_dev, s, &d_pts))) break;
+        if (dirs && (rc = stage_in(ar, dirs, n, on_dev, s, &d_dirs))) break;
+        T* d_out = out_n; uint8_t* d_keep = out_keep;
+        if (!on_dev) { if ((rc = aalloc(ar, &d_out, (size_t)n * 3))) break; if ((rc = aalloc(ar, &d_keep, (size_t)n))) break; }
+        GridIndex<T> gi;
+        if ((rc = index_alloc(ar, gi, n, occ, false, /*allow_bucketed=*/false))) break;
+        const T radius_t = (T)ball_radius;                          // RadiusResultSet<DistanceType = T>(radius, ...)
+        gi.h_want = sqrt((double)radius_t) / 1.98;                  // cells of about half the true search radius: 5^3 cells per point
+        if ((rc = index_build(gi, d_pts, occ, s))) break;
+        if (st) { st->n_grid_builds = 1; st->n_queries = n; st->n_passes = 1; }
+        const NormalsBallArgs<T> a{gi.gp, gi.sorted, gi.cell_start, d_dirs, (int)n, radius_t, ball_radius, min_pts, max_pts, weight_rbf, drop, d_out, d_keep};
+        hipLaunchKernelGGL(k_normals_ball<T>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        if (!on_dev) {
+            HIP_TRY(hipMemcpyAsync(out_n, d_out, (size_t)n * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ batches of pairs
 // BASELINE config 4 (256 independent 256k-vs-256k pairs): clouds this small leave every kernel at the launch floor, so a
 // batch keeps several pairs in flight, each on a lane of its own (stream + workspace + pinned result block): the fused calls
@@ -1576,6 +1679,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     for (pcu_hip_ctx* l : c->lanes) pcu_hip_ctx_destroy(l);
     c->lanes.clear();
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
+    if (c->aux) (void)hipFree(c->aux);
     if (c->arena) (void)hipFree(c->arena);
     kd_graph_drop(c);
     if (c->kd_ws) (void)hipFree(c->kd_ws);
@@ -1631,6 +1735,17 @@ int pcu_hip_chamfer_batch_##SUF(pcu_hip_ctx* c, int n_pairs, const T* const* xs,
 PCU_BATCH_CHAMFER(f32, float)
 PCU_BATCH_CHAMFER(f64, double)
 #undef PCU_BATCH_CHAMFER
+int pcu_hip_normals_knn_f32(pcu_hip_ctx* c, const float* p, int64_t n, const float* dirs, int k, int max_leaf, double drop, float* out_n, uint8_t* keep,
+                            unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return normals_knn_impl<float>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st); }
+int pcu_hip_normals_knn_f64(pcu_hip_ctx* c, const double* p, int64_t n, const double* dirs, int k, int max_leaf, double drop, double* out_n, uint8_t* keep,
+                            unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return normals_knn_impl<double>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st); }
+int pcu_hip_normals_ball_f32(pcu_hip_ctx* c, const float* p, int64_t n, const float* dirs, double radius, int min_pts, int max_pts, int weight_rbf, double drop,
+                             float* out_n, uint8_t* keep, unsigned flags, void* stream, pcu_hip_stats* st) {
+    DeviceGuard dg(c ? c->device : -1); return normals_ball_impl<float>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st); }
+int pcu_hip_normals_ball_f64(pcu_hip_ctx* c, const double* p, int64_t n, const double* dirs, double radius, int min_pts, int max_pts, int weight_rbf, double drop,
+                             double* out_n, uint8_t* keep, unsigned flags, void* stream, pcu_hip_stats* st) {
+    DeviceGuard dg(c ? c->device : -1); return normals_ball_impl<double>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st); }
+
 int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
 
 int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }

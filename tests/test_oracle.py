@@ -72,3 +72,22 @@ def test_reference_test_knn_body_on_oracle():
         assert np.all(np.abs(np.linalg.norm(a[:, None, :] - b[c], axis=-1) - d) < 1e-5)
     with pytest.raises(ValueError):
         oracle.k_nearest_neighbors(a, b, 0)
+
+
+def test_oracle_normals_on_planes():
+    """The numpy restatement of the normals path: exact planes give the plane normal, the view direction fixes the sign and
+    filters (src/point_cloud_normals.cpp:115-173)."""
+    rng = np.random.default_rng(2)
+    xy = rng.random((500, 2))
+    p = np.concatenate([xy, (0.5 * xy[:, :1] + 0.25 * xy[:, 1:2])], 1)           # plane z = 0.5 x + 0.25 y
+    n0 = np.array([-0.5, -0.25, 1.0]); n0 /= np.linalg.norm(n0)
+    idx, nrm, gap = oracle.normals_knn(p, 8)
+    assert len(idx) == 500 and np.allclose(np.abs(nrm @ n0), 1.0, atol=1e-9)
+    dirs = np.tile(-n0, (500, 1))
+    idx, nrm, _ = oracle.normals_knn(p, 8, view_directions=dirs)
+    assert len(idx) == 500 and np.allclose(nrm @ n0, -1.0, atol=1e-9)
+    idx, _, _ = oracle.normals_knn(p, 8, view_directions=np.tile(np.array([1.0, 0, 0]), (500, 1)), drop_angle_threshold=np.deg2rad(20))
+    assert len(idx) == 0                                                       # the normal is ~64 degrees off the x axis
+    idx, nrm, _ = oracle.normals_ball(p[:200], 0.05)
+    assert np.allclose(np.abs(nrm @ n0), 1.0, atol=1e-9)
+    assert len(oracle.normals_knn(p[:5], 9)[0]) == 0                           # fewer points than neighbours: dropped
