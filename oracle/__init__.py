@@ -242,3 +242,140 @@ def normals_ball(points, ball_radius, view_directions=None, drop_angle_threshold
         ok &= keep
     idx = np.flatnonzero(ok)
     return idx, normals[idx], gap[idx]
+
+
+# ---- Morton codes, voxel-grid downsampling, duplicate removal ------------------------------------------------
+
+def _morton_lib():
+    """oracle/_ref/libpcu_ref_morton.so: the reference's own src/common/morton_code.cpp behind oracle/ref_morton_shim.cpp."""
+    if "morton" not in _libs:
+        _libs["morton"] = _load(os.path.join(_HERE, "_ref", "libpcu_ref_morton.so"))
+    return _libs["morton"]
+
+
+def have_ref_morton():
+    return _morton_lib() is not None
+
+
+_M_SIGN = np.uint64(0x7000000000000000)
+_M_X = np.uint64(0x1249249249249249)
+
+
+def _split21(r):
+    r = r.astype(np.uint64)
+    for sh, mask in ((32, 0x1f00000000ffff), (16, 0x1f0000ff0000ff), (8, 0x100f00f00f00f00f), (4, 0x10c30c30c30c30c3), (2, 0x1249249249249249)):
+        r = (r | (r << np.uint64(sh))) & np.uint64(mask)
+    return r
+
+
+def _compact21(x):
+    d = x & np.uint64(0x1249249249249249)
+    for sh, mask in ((2, 0x10c30c30c30c30c3), (4, 0x100f00f00f00f00f), (8, 0x1f0000ff0000ff), (16, 0x1f00000000ffff)):
+        d = (d | (d >> np.uint64(sh))) & np.uint64(mask)
+    d = d | (d >> np.uint64(32))
+    d = np.where(d & np.uint64(0x100000), d | np.uint64(0xffe00000), d)
+    return d.astype(np.uint32).view(np.int32)
+
+
+def morton_encode(pts, kind="port"):
+    """src/morton.cpp:185-243 on MortonCode64(int32, int32, int32) (src/common/morton_code.cpp:46-66). kind "ref": the reference's
+    own class compiled in place; "port": numpy restatement."""
+    p = np.ascontiguousarray(np.asarray(pts).astype(np.int32))
+    if kind == "ref":
+        out = np.empty(p.shape[0], np.uint64)
+        _morton_lib().pcu_ref_morton_encode(_ptr(p), _c_i64(p.shape[0]), _ptr(out))
+        return out
+    u = p.view(np.uint32)
+    u = ((u & np.uint32(0x80000000)) >> np.uint32(11)) | (u & np.uint32(0x0fffff))
+    return (_split21(u[:, 0]) | (_split21(u[:, 1]) << np.uint64(1)) | (_split21(u[:, 2]) << np.uint64(2))) ^ _M_SIGN
+
+
+def morton_decode(codes, kind="port"):
+    c = np.ascontiguousarray(np.asarray(codes).astype(np.uint64))
+    if kind == "ref":
+        out = np.empty((c.shape[0], 3), np.int32)
+        _morton_lib().pcu_ref_morton_decode(_ptr(c), _c_i64(c.shape[0]), _ptr(out))
+        return out
+    d = c ^ _M_SIGN
+    return np.stack([_compact21(d), _compact21(d >> np.uint64(1)), _compact21(d >> np.uint64(2))], axis=1)
+
+
+def _morton_negate(data):
+    ym, zm = _M_X << np.uint64(1), _M_X << np.uint64(2)
+    d = ~data
+    one = np.uint64(1)
+    return (((d | ~_M_X) + one) & _M_X) | (((d | ~ym) + one) & ym) | (((d | ~zm) + one) & zm)
+
+
+def morton_addsub(c1, c2, subtract=False, kind="port"):
+    a = np.ascontiguousarray(np.asarray(c1).astype(np.uint64)); b = np.ascontiguousarray(np.asarray(c2).astype(np.uint64))
+    if kind == "ref":
+        out = np.empty(a.shape[0], np.uint64)
+        _morton_lib().pcu_ref_morton_addsub(_ptr(a), _ptr(b), _c_i64(a.shape[0]), _c_int(int(subtract)), _ptr(out))
+        return out
+    if subtract:
+        b = _morton_negate(b)
+    x1, x2 = a ^ _M_SIGN, b ^ _M_SIGN
+    ym, zm = _M_X << np.uint64(1), _M_X << np.uint64(2)
+    with np.errstate(over="ignore"):
+        xs = (x1 | ~_M_X) + (x2 & _M_X); ys = (x1 | ~ym) + (x2 & ym); zs = (x1 | ~zm) + (x2 & zm)
+    return ((xs & _M_X) | (ys & ym) | (zs & zm)) ^ _M_SIGN
+
+
+def morton_knn_window(codes, qcodes, k, kind="port"):
+    """The window of src/morton.cpp:362-383 (sort_dist=False semantics)."""
+    c = np.ascontiguousarray(np.asarray(codes).astype(np.uint64)); q = np.ascontiguousarray(np.asarray(qcodes).astype(np.uint64))
+    n = c.shape[0]; k = min(int(k), n)
+    if kind == "ref":
+        out = np.empty((q.shape[0], k), np.int64)
+        _morton_lib().pcu_ref_morton_knn_window(_ptr(c), _c_i64(n), _ptr(q), _c_i64(q.shape[0]), _c_int(k), _ptr(out))
+        return out
+    idx = np.searchsorted(c, q, side="left").astype(np.int64)
+    up, down = k // 2, k - k // 2
+    upper, lower = idx + up, idx - down
+    over = upper >= n
+    lower = np.where(over, lower - (upper - n), lower); upper = np.where(over, n, upper)
+    neg = lower < 0
+    upper = np.where(neg, upper - lower, upper); lower = np.where(neg, 0, lower)
+    return lower[:, None] + np.arange(k, dtype=np.int64)[None, :]
+
+
+def voxel_downsample(points, attrib, voxel_size, min_bound, min_points_per_voxel=1):
+    """downsample_point_cloud_to_voxels (src/sample_point_cloud.cpp:163-235) restated with a dict: sums in input order in the
+    input dtypes, mean = sum / count. Returns (v, attrib or None) sorted by voxel index (the reference's order is its hash table's)."""
+    p = np.ascontiguousarray(points); T = p.dtype.type
+    vs = np.asarray(voxel_size, dtype=p.dtype); mb = np.asarray(min_bound, dtype=p.dtype)
+    key = np.floor((p - mb) / vs).astype(np.int32)
+    acc = {}
+    for i in range(p.shape[0]):
+        k = (int(key[i, 0]), int(key[i, 1]), int(key[i, 2]))
+        e = acc.get(k)
+        if e is None:
+            e = acc[k] = [np.zeros(3, p.dtype), None if attrib is None else np.zeros(attrib.shape[1], attrib.dtype), 0]
+        e[0] = e[0] + p[i]
+        if attrib is not None:
+            e[1] = e[1] + attrib[i]
+        e[2] += 1
+    keys = sorted(k for k, e in acc.items() if e[2] >= min_points_per_voxel)
+    v = np.array([acc[k][0] / T(acc[k][2]) for k in keys], dtype=p.dtype).reshape(-1, 3)
+    a = None if attrib is None else np.array([acc[k][1] / attrib.dtype.type(acc[k][2]) for k in keys], dtype=attrib.dtype).reshape(-1, attrib.shape[1])
+    return v, a
+
+
+def deduplicate_point_cloud(points, epsilon):
+    """remove_duplicate_vertices (src/remove_duplicates.cpp:11-36): rows equal after round(V / eps) are one; unique rows in
+    lexicographic order (libigl unique_rows); representative = lowest input row (libigl's choice is not in the checkout)."""
+    p = np.ascontiguousarray(points)
+    r = p
+    if epsilon > 0:                       # igl::round = std::round: half away from zero (np.round is half-to-even)
+        q = p / p.dtype.type(epsilon)
+        t = np.trunc(q)
+        r = t + np.where(np.abs(q - t) >= 0.5, np.sign(q), 0).astype(p.dtype)      # q - trunc(q) is exact
+    r = r + p.dtype.type(0)
+    order = np.lexsort((np.arange(len(p)), r[:, 2], r[:, 1], r[:, 0]))
+    rs = r[order]
+    head = np.ones(len(p), bool); head[1:] = np.any(rs[1:] != rs[:-1], axis=1)
+    run = np.cumsum(head) - 1
+    svi = order[head].astype(np.int32)
+    svj = np.empty(len(p), np.int32); svj[order] = run
+    return p[svi], svi, svj

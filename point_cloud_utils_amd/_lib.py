@@ -85,6 +85,14 @@ def lib():
             getattr(L, "pcu_hip_chamfer_batch_" + suf).argtypes = [vp, ci, vp, vp, vp, vp, ctypes.c_double, ci, vp, u, vp, vp]
             getattr(L, "pcu_hip_normals_knn_" + suf).argtypes = [vp, vp, i64, vp, ci, ci, ctypes.c_double, vp, vp, u, vp, vp]
             getattr(L, "pcu_hip_normals_ball_" + suf).argtypes = [vp, vp, i64, vp, ctypes.c_double, ci, ci, ci, ctypes.c_double, vp, vp, u, vp, vp]
+        L.pcu_hip_morton_encode.argtypes = [vp, vp, i64, vp, u, vp]
+        L.pcu_hip_morton_decode.argtypes = [vp, vp, i64, vp, u, vp]
+        L.pcu_hip_morton_addsub.argtypes = [vp, vp, vp, i64, ci, vp, u, vp]
+        L.pcu_hip_morton_knn.argtypes = [vp, vp, i64, vp, i64, ci, ci, vp, u, vp]
+        for sp in ("f32", "f64"):
+            for sa in ("f32", "f64"):
+                getattr(L, f"pcu_hip_voxel_downsample_{sp}_{sa}").argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, u, vp]
+            getattr(L, "pcu_hip_dedup_" + sp).argtypes = [vp, vp, i64, ctypes.c_double, vp, vp, vp, vp, u, vp]
         L.pcu_hip_ctx_set_batch_lanes.argtypes = [vp, ci]
         L.pcu_hip_index_size.restype = ctypes.c_int64
         L.pcu_hip_index_size.argtypes = [vp]

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <stddef.h>
 #include <algorithm>
+#include <limits>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -22,6 +23,8 @@
 #include "search.h"
 #include "kd_order.h"
 #include "normals.h"
+#include "morton.h"
+#include "voxel.h"
 
 using namespace pcu;
 
@@ -1641,6 +1644,8 @@ static int debug_kd(pcu_hip_ctx* c, const T* pts, int64_t n, int leaf_max, int64
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
 
+#include "voxel_host.h"
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1745,6 +1750,27 @@ int pcu_hip_normals_ball_f32(pcu_hip_ctx* c, const float* p, int64_t n, const fl
 int pcu_hip_normals_ball_f64(pcu_hip_ctx* c, const double* p, int64_t n, const double* dirs, double radius, int min_pts, int max_pts, int weight_rbf, double drop,
                              double* out_n, uint8_t* keep, unsigned flags, void* stream, pcu_hip_stats* st) {
     DeviceGuard dg(c ? c->device : -1); return normals_ball_impl<double>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st); }
+
+int pcu_hip_morton_encode(pcu_hip_ctx* c, const int32_t* pts, int64_t n, uint64_t* codes, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<int32_t, int32_t>(c, 0, pts, nullptr, n, codes, flags, stream); }
+int pcu_hip_morton_decode(pcu_hip_ctx* c, const uint64_t* codes, int64_t n, int32_t* pts, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<uint64_t, uint64_t>(c, 1, codes, nullptr, n, pts, flags, stream); }
+int pcu_hip_morton_addsub(pcu_hip_ctx* c, const uint64_t* c1, const uint64_t* c2, int64_t n, int subtract, uint64_t* out, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<uint64_t, uint64_t>(c, subtract ? 3 : 2, c1, c2, n, out, flags, stream); }
+int pcu_hip_morton_knn(pcu_hip_ctx* c, const uint64_t* codes, int64_t n, const uint64_t* qcodes, int64_t m, int k, int sort_dist, int64_t* out_nn, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return morton_knn_impl<uint64_t>(c, codes, n, qcodes, m, k, sort_dist, out_nn, flags, stream); }
+#define PCU_VOXEL(SUF, T, A)                                                                                                                        \
+int pcu_hip_voxel_downsample_##SUF(pcu_hip_ctx* c, const T* pts, int64_t n, const A* attrib, int64_t attrib_rows, int attrib_cols, const double* voxel_size3,  \
+                                   const double* min_bound3, const double* max_bound3, int min_points_per_voxel, T* out_v, A* out_attrib, int64_t* out_count,  \
+                                   unsigned flags, void* stream) {                                                                                  \
+    DeviceGuard dg(c ? c->device : -1);                                                                                                             \
+    return voxel_downsample_impl<T, A>(c, pts, n, attrib, attrib_rows, attrib_cols, voxel_size3, min_bound3, max_bound3, min_points_per_voxel, out_v, out_attrib, out_count, flags, stream); }
+PCU_VOXEL(f32_f32, float, float) PCU_VOXEL(f32_f64, float, double) PCU_VOXEL(f64_f32, double, float) PCU_VOXEL(f64_f64, double, double)
+#undef PCU_VOXEL
+int pcu_hip_dedup_f32(pcu_hip_ctx* c, const float* pts, int64_t n, double epsilon, float* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return dedup_impl<float>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
+int pcu_hip_dedup_f64(pcu_hip_ctx* c, const double* pts, int64_t n, double epsilon, double* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
+    DeviceGuard dg(c ? c->device : -1); return dedup_impl<double>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
 
 int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
 

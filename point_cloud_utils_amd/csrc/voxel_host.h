@@ -1,0 +1,217 @@
+// csrc/voxel_host.h -- host orchestration of the SURVEY.md 8f-4 operators (included by pcu_hip.hip after the context / arena
+// helpers): Morton codes (morton.h), voxel-grid downsampling and duplicate removal (voxel.h).
+#pragma once
+
+template <typename U>
+static int stage_any(Arena& ar, const U* p, size_t count, bool on_dev, hipStream_t s, const U** out) {
+    if (on_dev) { *out = p; return 0; }
+    U* d = nullptr;
+    if (aalloc(ar, &d, count)) return -1;
+    HIP_TRY(hipMemcpyAsync(d, p, count * sizeof(U), hipMemcpyHostToDevice, s));
+    *out = d;
+    return 0;
+}
+static hipStream_t pick_stream(pcu_hip_ctx* c, unsigned flags, void* stream) {
+    return (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
+}
+
+// ---------------------------------------------------------------------------------------------------- Morton codes
+// kind: 0 encode (in: I (n,3) -> out u64 (n)), 1 decode (in: C (n) -> out i32 (n,3)), 2 add, 3 subtract (in, in2: C (n) -> u64 (n))
+template <typename In, typename In2>
+static int morton_map_impl(pcu_hip_ctx* c, int kind, const In* in, const In2* in2, int64_t n, void* out, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (n <= 0) return fail(PCU_HIP_ERR_INVALID, kind == 0 ? "pts must be an array of shape [n, 3] but got an empty array"
+                                                 : kind == 1 ? "codes must be an array of shape [n] but got an empty array"
+                                                             : "codes_1 must be an array of shape [n,] but got an empty array");
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    const size_t in_count = kind == 0 ? (size_t)n * 3 : (size_t)n, out_bytes = kind == 1 ? (size_t)n * 12 : (size_t)n * 8;
+    if (ctx_begin(c, on_dev ? 4096 : align_up(in_count * sizeof(In), 256) + align_up((size_t)n * sizeof(In2), 256) + align_up(out_bytes, 256) + 4096)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const In* d_in; const In2* d_in2 = in2;
+        if ((rc = stage_any(ar, in, in_count, on_dev, s, &d_in))) break;
+        if (kind >= 2 && (rc = stage_any(ar, in2, (size_t)n, on_dev, s, &d_in2))) break;
+        void* d_out = out;
+        if (!on_dev) { char* t = nullptr; if ((rc = aalloc(ar, &t, out_bytes))) break; d_out = t; }
+        const int blocks = (int)std::min<int64_t>((n + 255) / 256, 65536);
+        if (kind == 0) hipLaunchKernelGGL((k_morton_encode<In>), dim3(blocks), dim3(256), 0, s, d_in, (long long)n, (uint64_t*)d_out);
+        else if (kind == 1) hipLaunchKernelGGL((k_morton_decode<In>), dim3(blocks), dim3(256), 0, s, d_in, (long long)n, (int32_t*)d_out);
+        else hipLaunchKernelGGL((k_morton_addsub<In, In2>), dim3(blocks), dim3(256), 0, s, d_in, d_in2, (long long)n, kind == 3 ? 1 : 0, (uint64_t*)d_out);
+        HIP_TRY(hipGetLastError());
+        if (!on_dev) HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename C>
+static int morton_knn_impl(pcu_hip_ctx* c, const C* codes, int64_t n, const C* qcodes, int64_t m, int k, int sort_dist, int64_t* out_nn, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (k <= 0) return fail(PCU_HIP_ERR_INVALID, "k must be greater than 0");
+    if (n <= 0 || m <= 0) return fail(PCU_HIP_ERR_INVALID, "codes must be an array of shape [n] but got an empty array");
+    if (k > n) k = (int)n;                                   // k = std::min(k, (int)codes.rows()), src/morton.cpp:362
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    if (ctx_begin(c, on_dev ? 4096 : align_up((size_t)n * sizeof(C), 256) + align_up((size_t)m * sizeof(C), 256) + align_up((size_t)m * k * 8, 256) + 4096)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const C *d_codes, *d_q;
+        if ((rc = stage_any(ar, codes, (size_t)n, on_dev, s, &d_codes)) || (rc = stage_any(ar, qcodes, (size_t)m, on_dev, s, &d_q))) break;
+        long long* d_nn = (long long*)out_nn;
+        if (!on_dev && (rc = aalloc(ar, &d_nn, (size_t)m * k))) break;
+        hipLaunchKernelGGL((k_morton_knn<C>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_codes, (long long)n, d_q, (long long)m, k, sort_dist, d_nn);
+        HIP_TRY(hipGetLastError());
+        if (!on_dev) HIP_TRY(hipMemcpyAsync(out_nn, d_nn, (size_t)m * k * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- sort by a key triple
+// perm_out: point ids ordered lexicographically by (k0, k1, k2), equal triples in input order. Three stable LSD passes
+// (rocPRIM radix sort of (key, id) pairs), least significant component first; ids must hold 0..n-1 on entry.
+template <typename K>
+static int sort_by_triple(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, unsigned* ids, int n, unsigned** perm_out) {
+    K *ka = nullptr, *kb = nullptr; unsigned* alt = nullptr;
+    if (aalloc(ar, &ka, (size_t)n) || aalloc(ar, &kb, (size_t)n) || aalloc(ar, &alt, (size_t)n)) return -1;
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, ids, alt, (size_t)n, 0u, (unsigned)(8 * sizeof(K)), s));
+    char* tmp = nullptr;
+    if (aalloc(ar, &tmp, tmp_bytes + 256)) return -1;
+    const K* comps[3] = {k2, k1, k0};
+    unsigned *cur = ids, *nxt = alt;
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL((k_gather_keys<K>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, comps[pass], cur, n, ka);
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, ka, kb, cur, nxt, (size_t)n, 0u, (unsigned)(8 * sizeof(K)), s));
+        std::swap(cur, nxt);
+    }
+    HIP_TRY(hipGetLastError());
+    *perm_out = cur;
+    return 0;
+}
+// head flags + inclusive scan of a sorted order -> (flag, scan); the number of runs is scan[n-1]
+template <typename K>
+static int runs_of(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, const unsigned* perm, int n, unsigned** flag_out, unsigned** scan_out) {
+    unsigned *flag = nullptr, *scan = nullptr;
+    if (aalloc(ar, &flag, (size_t)n) || aalloc(ar, &scan, (size_t)n + 1)) return -1;
+    hipLaunchKernelGGL((k_run_heads<K>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, k0, k1, k2, perm, n, flag);
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, flag, scan, (size_t)n, rocprim::plus<unsigned>(), s));
+    char* tmp = nullptr;
+    if (aalloc(ar, &tmp, tmp_bytes + 256)) return -1;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, flag, scan, (size_t)n, rocprim::plus<unsigned>(), s));
+    *flag_out = flag; *scan_out = scan;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- voxel-grid downsampling
+// downsample_point_cloud_voxel_grid_internal (src/sample_point_cloud.cpp:336-368). out_v (n,3) / out_a (n,cols): caller-sized for the
+// worst case; *out_count = number of voxels written.
+template <typename T, typename A>
+static int voxel_downsample_impl(pcu_hip_ctx* c, const T* pts, int64_t n, const A* attrib, int64_t attrib_rows, int cols, const double* vsize, const double* vmin,
+                                 const double* vmax, int min_pts, T* out_v, A* out_a, int64_t* out_count, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (n <= 0) { *out_count = 0; return 0; }
+    if (n > 0x7ffffff0ll) return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^31-16 rows are not supported");
+    const T vs[3] = {(T)vsize[0], (T)vsize[1], (T)vsize[2]}, mn[3] = {(T)vmin[0], (T)vmin[1], (T)vmin[2]}, mx[3] = {(T)vmax[0], (T)vmax[1], (T)vmax[2]};
+    for (int i = 0; i < 3; ++i) {                            // :174-181
+        if (vs[i] <= 0.0) return fail(PCU_HIP_ERR_INVALID, "Voxel size is negative");
+        if (vs[i] * (T)std::numeric_limits<int>::max() < (T)(mx[i] - mn[i])) return fail(PCU_HIP_ERR_INVALID, "Voxel size is too small");
+    }
+    const bool has_attr = attrib && attrib_rows != 0 && cols != 0;
+    if (has_attr && attrib_rows != n)
+        return fail(PCU_HIP_ERR_INVALID, "Invalid number of attributes (%lld). Must match number of input vertices (%lld) or be 0.", (long long)attrib_rows, (long long)n);
+    if (!has_attr) cols = 0;
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    const size_t N = (size_t)n;
+    size_t need = 16 * align_up(N * 4, 256) + (1 << 20) + (on_dev ? 0 : 2 * (align_up(N * 3 * sizeof(T), 256) + align_up(N * (size_t)cols * sizeof(A), 256)));
+    if (ctx_begin(c, need + 65536)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T* d_pts; const A* d_attr = attrib;
+        if ((rc = stage_any(ar, pts, N * 3, on_dev, s, &d_pts))) break;
+        if (has_attr && (rc = stage_any(ar, attrib, N * (size_t)cols, on_dev, s, &d_attr))) break;
+        T* d_out_v = out_v; A* d_out_a = out_a;
+        if (!on_dev) { if ((rc = aalloc(ar, &d_out_v, N * 3))) break; if (has_attr && (rc = aalloc(ar, &d_out_a, N * (size_t)cols))) break; }
+        int *k0 = nullptr, *k1 = nullptr, *k2 = nullptr; unsigned* ids = nullptr;
+        if ((rc = aalloc(ar, &k0, N)) || (rc = aalloc(ar, &k1, N)) || (rc = aalloc(ar, &k2, N)) || (rc = aalloc(ar, &ids, N))) break;
+        const int nb = (int)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((k_voxel_keys<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, (int)n, vs[0], vs[1], vs[2], mn[0], mn[1], mn[2], k0, k1, k2, ids);
+        unsigned *perm = nullptr, *flag = nullptr, *scan = nullptr;
+        if ((rc = sort_by_triple<int>(ar, s, k0, k1, k2, ids, (int)n, &perm))) break;
+        if ((rc = runs_of<int>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan))) break;
+        unsigned *start = nullptr, *keep = nullptr, *keep_scan = nullptr;
+        if ((rc = aalloc(ar, &start, N + 1)) || (rc = aalloc(ar, &keep, N)) || (rc = aalloc(ar, &keep_scan, N))) break;
+        hipLaunchKernelGGL(k_run_starts, dim3(nb), dim3(kBlock), 0, s, flag, scan, (int)n, start);
+        const unsigned* n_runs_dev = scan + (n - 1);
+        HIP_TRY(hipMemsetAsync(keep, 0, N * 4, s));
+        hipLaunchKernelGGL(k_run_keep, dim3(nb), dim3(kBlock), 0, s, start, n_runs_dev, min_pts, keep);
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, keep, keep_scan, N, rocprim::plus<unsigned>(), s));
+        char* tmp = nullptr;
+        if ((rc = aalloc(ar, &tmp, tmp_bytes + 256))) break;
+        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, N, rocprim::plus<unsigned>(), s));
+        hipLaunchKernelGGL((k_voxel_means<T, A>), dim3(nb), dim3(kBlock), 0, s, d_pts, d_attr, cols, perm, start, n_runs_dev, keep, keep_scan, d_out_v, d_out_a);
+        HIP_TRY(hipGetLastError());
+        unsigned n_out = 0;
+        HIP_TRY(hipMemcpyAsync(&n_out, keep_scan + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *out_count = (int64_t)n_out;
+        if (!on_dev && n_out) {
+            HIP_TRY(hipMemcpyAsync(out_v, d_out_v, (size_t)n_out * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+            if (has_attr) HIP_TRY(hipMemcpyAsync(out_a, d_out_a, (size_t)n_out * cols * sizeof(A), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- duplicate removal
+// deduplicate_point_cloud (src/remove_duplicates.cpp:108-129). out_pts (n,3), out_svi (n) worst case; out_svj (n); *out_count = unique rows.
+template <typename T>
+static int dedup_impl(pcu_hip_ctx* c, const T* pts, int64_t n, double epsilon, T* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (n <= 0) { *out_count = 0; return 0; }
+    if (n > 0x7ffffff0ll) return fail(PCU_HIP_ERR_INVALID, "point clouds with more than 2^31-16 rows are not supported");
+    typedef typename EncT<T>::type K;
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    const size_t N = (size_t)n;
+    if (ctx_begin(c, 8 * align_up(N * sizeof(K), 256) + 8 * align_up(N * 4, 256) + (1 << 20) + (on_dev ? 0 : 3 * align_up(N * 3 * sizeof(T), 256)) + 65536)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T* d_pts;
+        if ((rc = stage_any(ar, pts, N * 3, on_dev, s, &d_pts))) break;
+        T* d_out = out_pts; int *d_svi = out_svi, *d_svj = out_svj;
+        if (!on_dev) { if ((rc = aalloc(ar, &d_out, N * 3)) || (rc = aalloc(ar, &d_svi, N)) || (rc = aalloc(ar, &d_svj, N))) break; }
+        K *k0 = nullptr, *k1 = nullptr, *k2 = nullptr; unsigned* ids = nullptr;
+        if ((rc = aalloc(ar, &k0, N)) || (rc = aalloc(ar, &k1, N)) || (rc = aalloc(ar, &k2, N)) || (rc = aalloc(ar, &ids, N))) break;
+        const int nb = (int)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((k_round_keys<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, (int)n, (T)epsilon, k0, k1, k2, ids);
+        unsigned *perm = nullptr, *flag = nullptr, *scan = nullptr;
+        if ((rc = sort_by_triple<K>(ar, s, k0, k1, k2, ids, (int)n, &perm))) break;
+        if ((rc = runs_of<K>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan))) break;
+        hipLaunchKernelGGL((k_dedup_write<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, perm, flag, scan, (int)n, d_out, d_svi, d_svj);
+        HIP_TRY(hipGetLastError());
+        unsigned n_out = 0;
+        HIP_TRY(hipMemcpyAsync(&n_out, scan + (n - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *out_count = (int64_t)n_out;
+        if (!on_dev) {
+            HIP_TRY(hipMemcpyAsync(out_pts, d_out, (size_t)n_out * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_svi, d_svi, (size_t)n_out * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_svj, d_svj, N * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}

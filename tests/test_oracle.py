@@ -91,3 +91,38 @@ def test_oracle_normals_on_planes():
     idx, nrm, _ = oracle.normals_ball(p[:200], 0.05)
     assert np.allclose(np.abs(nrm @ n0), 1.0, atol=1e-9)
     assert len(oracle.normals_knn(p[:5], 9)[0]) == 0                           # fewer points than neighbours: dropped
+
+
+def test_oracle_morton_port_pinned_to_reference():
+    """The numpy restatement of MortonCode64 against the reference's own class (src/common/morton_code.cpp compiled in place
+    into oracle/_ref/libpcu_ref_morton.so) -- skipped where /root/reference never existed."""
+    if not oracle.have_ref_morton():
+        pytest.skip("oracle/_ref/libpcu_ref_morton.so not built (no /root/reference)")
+    rng = np.random.default_rng(0)
+    p = rng.integers(-(1 << 20), 1 << 20, (50000, 3)).astype(np.int32)
+    p[:4] = [[0, 0, 0], [-1, -1, -1], [(1 << 20) - 1] * 3, [-(1 << 20)] * 3]
+    c = oracle.morton_encode(p, "ref")
+    assert np.array_equal(c, oracle.morton_encode(p, "port"))
+    assert np.array_equal(oracle.morton_decode(c, "ref"), p) and np.array_equal(oracle.morton_decode(c, "port"), p)
+    c2 = oracle.morton_encode(rng.integers(-2000, 2000, (50000, 3)).astype(np.int32), "ref")
+    for sub in (False, True):
+        assert np.array_equal(oracle.morton_addsub(c, c2, sub, "ref"), oracle.morton_addsub(c, c2, sub, "port"))
+    cs = np.sort(c)
+    for k in (1, 7, 16):
+        assert np.array_equal(oracle.morton_knn_window(cs, c2[:2000], k, "ref"), oracle.morton_knn_window(cs, c2[:2000], k, "port"))
+    assert np.array_equal(oracle.morton_knn_window(cs[:10], c2[:100], 15, "ref"), oracle.morton_knn_window(cs[:10], c2[:100], 15, "port"))
+
+
+def test_oracle_voxel_and_dedup_restatements():
+    rng = np.random.default_rng(1)
+    p = rng.random((2000, 3)).astype(np.float32)
+    v, a = oracle.voxel_downsample(p, p * 2, [0.25] * 3, [0, 0, 0])
+    assert len(v) == 64 and np.allclose(a, v * 2, rtol=1e-6)
+    key = np.floor(p / np.float32(0.25)).astype(int)
+    m = np.all(key == 0, axis=1)
+    assert np.allclose(v[0], p[m].mean(0), rtol=1e-5)
+    x = np.concatenate([p[:100], p[:100]])
+    u, svi, svj = oracle.deduplicate_point_cloud(x, 1e-7)
+    assert len(u) == 100 and np.array_equal(x[svi], u) and np.array_equal(u[svj], x) and np.all(svi < 100)
+    assert np.array_equal(oracle.deduplicate_point_cloud(np.array([[0.5, 1.5, -0.5], [2.5, -1.5, 0.49999997]], np.float32), 1.0)[0],
+                          np.array([[0.5, 1.5, -0.5], [2.5, -1.5, 0.49999997]], np.float32)[[0, 1]])
