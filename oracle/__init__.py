@@ -379,3 +379,62 @@ def deduplicate_point_cloud(points, epsilon):
     svi = order[head].astype(np.int32)
     svj = np.empty(len(p), np.int32); svj[order] = run
     return p[svi], svi, svj
+
+
+# ---- numpy restatement of point_cloud_utils/_sinkhorn.py (the reference module is pure numpy; it is imported
+# from /root/reference where that exists to pin this restatement and to generate tests/golden/sinkhorn.npz) -------------------
+
+def pairwise_distances(a, b, p=None):
+    """_sinkhorn.py:4-33."""
+    squeezed = False
+    if len(a.shape) == 2 and len(b.shape) == 2:
+        a = a[np.newaxis]; b = b[np.newaxis]; squeezed = True
+    ret = np.linalg.norm(a[:, :, np.newaxis, :] - b[:, np.newaxis, :, :], axis=-1, ord=p)
+    return np.squeeze(ret) if squeezed else ret
+
+
+def sinkhorn(a, b, M, eps, max_iters=100, stop_thresh=1e-3):
+    """_sinkhorn.py:36-130 (argument checks omitted). Returns (P, iterations run)."""
+    M = np.squeeze(M); a = np.squeeze(a); b = np.squeeze(b)
+    squeezed = False
+    if M.ndim == 2:
+        M = M[np.newaxis]; a = a[np.newaxis]; b = b[np.newaxis]; squeezed = True
+    u = np.zeros_like(a); v = np.zeros_like(b)
+    Mt = np.transpose(M, axes=(0, 2, 1))
+
+    def lse(x):
+        mx = x.max(2)
+        return np.log(np.sum(np.exp(x - mx[:, :, np.newaxis]), axis=2)) + mx
+
+    iters = 0
+    for _ in range(max_iters):
+        up, vp = u, v
+        u = eps * (np.log(a) - lse((-M + np.expand_dims(v, 1)) / eps))
+        v = eps * (np.log(b) - lse((-Mt + np.expand_dims(u, 1)) / eps))
+        iters += 1
+        if np.sum(np.abs(up - u), axis=1).max() < stop_thresh and np.sum(np.abs(vp - v), axis=1).max() < stop_thresh:
+            break
+    P = np.exp((-M + np.expand_dims(u, 2) + np.expand_dims(v, 1)) / eps)
+    return (np.squeeze(P) if squeezed else P), iters
+
+
+def earth_movers_distance(p, q, p_norm=2, eps=1e-4, max_iters=100, stop_thresh=1e-3):
+    """_sinkhorn.py:133-156."""
+    M = pairwise_distances(p, q, p_norm)
+    a = np.ones(p.shape[0]) / p.shape[0]; b = np.ones(q.shape[0]) / q.shape[0]
+    if a.dtype != M.dtype:
+        raise ValueError("Tensors a, b, and M must have the same dtype")
+    P, _ = sinkhorn(a, b, M, eps, max_iters, stop_thresh)
+    return (P * M).sum(), P
+
+
+def reference_sinkhorn_module():
+    """The reference's own _sinkhorn.py, loaded from /root/reference (None where it does not exist, e.g. on the GPU box)."""
+    path = "/root/reference/point_cloud_utils/_sinkhorn.py"
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_pcu_ref_sinkhorn", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

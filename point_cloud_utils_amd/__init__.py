@@ -30,6 +30,7 @@ __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_dis
            "estimate_point_cloud_normals_knn", "estimate_point_cloud_normals_ball",
            "morton_encode", "morton_decode", "morton_add", "morton_subtract", "morton_knn",
            "downsample_point_cloud_on_voxel_grid", "deduplicate_point_cloud",
+           "pairwise_distances", "sinkhorn", "earth_movers_distance",
            "last_stats", "set_timing", "set_cell_occupancy", "device_count", "DatasetIndex"]
 
 _last_stats = [None]      # the Stats struct of the most recent call (turned into a dict on demand)
@@ -426,3 +427,4 @@ class DatasetIndex:
 from ._normals import estimate_point_cloud_normals_knn, estimate_point_cloud_normals_ball  # noqa: E402,F401
 from ._voxel import (morton_encode, morton_decode, morton_add, morton_subtract, morton_knn,  # noqa: E402,F401
                      downsample_point_cloud_on_voxel_grid, deduplicate_point_cloud)
+from ._sinkhorn import pairwise_distances, sinkhorn, earth_movers_distance  # noqa: E402,F401

@@ -93,6 +93,10 @@ def lib():
             for sa in ("f32", "f64"):
                 getattr(L, f"pcu_hip_voxel_downsample_{sp}_{sa}").argtypes = [vp, vp, i64, vp, i64, ci, vp, vp, vp, ci, vp, vp, vp, u, vp]
             getattr(L, "pcu_hip_dedup_" + sp).argtypes = [vp, vp, i64, ctypes.c_double, vp, vp, vp, vp, u, vp]
+        for sp in ("f32", "f64"):
+            getattr(L, "pcu_hip_pairwise_" + sp).argtypes = [vp, vp, vp, i64, i64, i64, i64, ctypes.c_double, vp, u, vp]
+            getattr(L, "pcu_hip_sinkhorn_" + sp).argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_double, ci, ctypes.c_double, vp, vp, u, vp]
+            getattr(L, "pcu_hip_dot_" + sp).argtypes = [vp, vp, vp, i64, vp, u, vp]
         L.pcu_hip_ctx_set_batch_lanes.argtypes = [vp, ci]
         L.pcu_hip_index_size.restype = ctypes.c_int64
         L.pcu_hip_index_size.argtypes = [vp]

@@ -25,6 +25,7 @@
 #include "normals.h"
 #include "morton.h"
 #include "voxel.h"
+#include "sinkhorn.h"
 
 using namespace pcu;
 
@@ -1771,6 +1772,17 @@ int pcu_hip_dedup_f32(pcu_hip_ctx* c, const float* pts, int64_t n, double epsilo
     DeviceGuard dg(c ? c->device : -1); return dedup_impl<float>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
 int pcu_hip_dedup_f64(pcu_hip_ctx* c, const double* pts, int64_t n, double epsilon, double* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
     DeviceGuard dg(c ? c->device : -1); return dedup_impl<double>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
+
+#define PCU_SINK(SUF, T)                                                                                                                             \
+int pcu_hip_pairwise_##SUF(pcu_hip_ctx* c, const T* a, const T* b, int64_t nb, int64_t m, int64_t n, int64_t d, double p_norm, T* out, unsigned flags, void* stream) {  \
+    DeviceGuard dg(c ? c->device : -1); return pairwise_impl<T>(c, a, b, nb, m, n, d, p_norm, out, flags, stream); }                                 \
+int pcu_hip_sinkhorn_##SUF(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int64_t nb, int64_t m, int64_t n, double eps, int max_iters, double stop_thresh,  \
+                           T* out_P, int* out_iters, unsigned flags, void* stream) {                                                                 \
+    DeviceGuard dg(c ? c->device : -1); return sinkhorn_impl<T>(c, a, b, M, nb, m, n, eps, max_iters, stop_thresh, out_P, out_iters, flags, stream); } \
+int pcu_hip_dot_##SUF(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, double* out, unsigned flags, void* stream) {                            \
+    DeviceGuard dg(c ? c->device : -1); return dot_impl<T>(c, x, y, count, out, flags, stream); }
+PCU_SINK(f32, float) PCU_SINK(f64, double)
+#undef PCU_SINK
 
 int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
 

@@ -1,0 +1,158 @@
+// csrc/sinkhorn.h -- dense pairwise distances and Sinkhorn iterations: the one dense N x M workload of the
+// path's neighbourhood, HBM-bound (every Sinkhorn iteration streams the (nb, m, n) cost matrix twice: 2 m n s bytes).
+//
+// Replaces point_cloud_utils/_sinkhorn.py (pure numpy in the reference):
+//   pairwise_distances :4-33    M[b,i,j] = || a[b,i,:] - b[b,j,:] ||_p   (numpy.linalg.norm(..., axis=-1, ord=p))
+//   sinkhorn           :36-130  log-domain Sinkhorn: u <- eps (log a - LSE_j((-M + v_j) / eps)), v <- eps (log b - LSE_i((-M + u_i) / eps)),
+//                               stop when both max_b sum |du|, max_b sum |dv| < stop_thresh; P = exp((-M + u_i + v_j) / eps)
+//   earth_movers_distance :133-156  (P * M).sum()
+// Arithmetic is done in the input dtype with the reference's operation order per element ((-M + v) / eps, exp(x - max), ...);
+// what differs is the ORDER OF THE SUMS (numpy: pairwise blocks; here: fixed trees over a block, and a streaming
+// log-sum-exp for the column pass so that the matrix is read once per pass). Tolerance: 1e-5 relative for float32, 1e-11 for
+// float64 on u, v, P (tests/test_gpu_sinkhorn.py). All reductions run in a fixed order: results are reproducible run to run.
+#pragma once
+#include "pcu_types.h"
+#include "grid.h"
+#include "reduce.h"
+
+namespace pcu {
+
+// ---- pairwise distances ----------------------------------------------------------------------------------------------------
+// one thread per output element; a block covers 64 consecutive j of 4 consecutive i (coalesced stores, the a rows and b rows it
+// reads are shared through L1)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pairwise(const T* __restrict__ a, const T* __restrict__ b, int m, int n, int d, int pcode, double p, T* __restrict__ out) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6), bt = blockIdx.z;
+    if (i >= m || j >= n) return;
+    const T* ai = a + ((size_t)bt * m + i) * d; const T* bj = b + ((size_t)bt * n + j) * d;
+    T acc = pcode == P_NINF ? (T)INFINITY : (T)0;
+    for (int c = 0; c < d; ++c) {
+        const T x = ai[c] - bj[c];
+        const T ax = x < 0 ? -x : x;
+        if (pcode == P_TWO) acc += x * x;                       // sqrt(add.reduce(x * x)) -- numpy's 2-norm of a real vector
+        else if (pcode == P_ONE) acc += ax;
+        else if (pcode == P_INF) acc = ax > acc ? ax : acc;
+        else if (pcode == P_NINF) acc = ax < acc ? ax : acc;
+        else if (pcode == P_ZERO) acc += (T)(x != 0);
+        else acc += (T)pow((double)ax, p);
+    }
+    if (pcode == P_TWO) acc = sqrt(acc);
+    else if (pcode == P_GEN) acc = (T)pow((double)acc, 1.0 / p);
+    out[((size_t)bt * m + i) * n + j] = acc;
+}
+
+// ---- Sinkhorn ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct SinkArgs {
+    const T* a; const T* b; const T* M;     // (nb,m), (nb,n), (nb,m,n)
+    T* u; T* v; T* du; T* dv;               // potentials and |change| of the current iteration
+    int nb, m, n;
+    T eps;
+    int* done;                              // device flag: set once both errors are below the threshold; later launches exit at once
+};
+
+template <typename T> __device__ __forceinline__ T blk_max(T v, T* s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = s[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = s[w] > r ? s[w] : r;
+    return r;
+}
+template <typename T> __device__ __forceinline__ T blk_sum(T v, T* s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = s[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += s[w];
+    return r;
+}
+
+// u update (:113-114): one block per (batch, row). Two sweeps over the row (max, then sum of exp(x - max)) as
+// stabilized_log_sum_exp does (:106-110); the second sweep re-reads the row from cache.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sink_rows(const SinkArgs<T> s) {
+    if (*s.done) return;
+    __shared__ T sm[4];
+    const int i = blockIdx.x, bt = blockIdx.y;
+    const T* Mrow = s.M + ((size_t)bt * s.m + i) * s.n; const T* v = s.v + (size_t)bt * s.n;
+    T mx = -(T)INFINITY;
+    for (int j = threadIdx.x; j < s.n; j += 256) { const T x = (-Mrow[j] + v[j]) / s.eps; mx = x > mx ? x : mx; }
+    mx = blk_max(mx, sm);
+    T acc = 0;
+    for (int j = threadIdx.x; j < s.n; j += 256) { const T x = (-Mrow[j] + v[j]) / s.eps; acc += exp(x - mx); }
+    acc = blk_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        const T lse = log(acc) + mx;
+        const size_t o = (size_t)bt * s.m + i;
+        const T un = s.eps * (log(s.a[o]) - lse);
+        const T d = s.u[o] - un;
+        s.du[o] = d < 0 ? -d : d; s.u[o] = un;
+    }
+}
+// v update (:116-117): a block owns 32 consecutive columns, 32 thread rows stride over i. The column sums use a streaming
+// log-sum-exp (running maximum, rescaled sum), so M is read once; the 32 partial (max, sum) pairs of a column are merged in LDS.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s) {
+    if (*s.done) return;
+    __shared__ T s_mx[32][33], s_sum[32][33];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5, j = blockIdx.x * 32 + c, bt = blockIdx.y;
+    const T* Mb = s.M + (size_t)bt * s.m * s.n; const T* u = s.u + (size_t)bt * s.m;
+    T mx = -(T)INFINITY, acc = 0;
+    if (j < s.n)
+        for (int i = r; i < s.m; i += 32) {
+            const T x = (-Mb[(size_t)i * s.n + j] + u[i]) / s.eps;
+            if (x > mx) { acc = acc * exp(mx - x) + (T)1; mx = x; } else acc += exp(x - mx);
+        }
+    s_mx[r][c] = mx; s_sum[r][c] = acc;
+    __syncthreads();
+    if (r == 0 && j < s.n) {
+        T M2 = s_mx[0][c];
+        for (int k = 1; k < 32; ++k) M2 = s_mx[k][c] > M2 ? s_mx[k][c] : M2;
+        T tot = 0;
+        for (int k = 0; k < 32; ++k) tot += s_mx[k][c] == -(T)INFINITY ? (T)0 : s_sum[k][c] * exp(s_mx[k][c] - M2);
+        const T lse = log(tot) + M2;
+        const size_t o = (size_t)bt * s.n + j;
+        const T vn = s.eps * (log(s.b[o]) - lse);
+        const T d = s.v[o] - vn;
+        s.dv[o] = d < 0 ? -d : d; s.v[o] = vn;
+    }
+}
+// err_u = max_b sum_i |du| , err_v likewise (:119-120); done when both are below the threshold (:122-123). One block.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sink_check(const SinkArgs<T> s, T stop_thresh, int* iters) {
+    if (*s.done) return;
+    __shared__ T sm[16];
+    T eu = 0, ev = 0;
+    for (int bt = 0; bt < s.nb; ++bt) {
+        T a = 0, b = 0;
+        for (int i = threadIdx.x; i < s.m; i += 1024) a += s.du[(size_t)bt * s.m + i];
+        for (int j = threadIdx.x; j < s.n; j += 1024) b += s.dv[(size_t)bt * s.n + j];
+        a = blk_sum(a, sm); b = blk_sum(b, sm);
+        eu = a > eu ? a : eu; ev = b > ev ? b : ev;
+    }
+    if (threadIdx.x == 0) { *iters += 1; if (eu < stop_thresh && ev < stop_thresh) *s.done = 1; }
+}
+// P = exp((-M + u_i + v_j) / eps) (:125-127)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sink_plan(const SinkArgs<T> s, T* __restrict__ P) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, bt = blockIdx.z;
+    if (j >= s.n) return;
+    const size_t o = ((size_t)bt * s.m + i) * s.n + j;
+    P[o] = exp(((-s.M[o] + s.u[(size_t)bt * s.m + i]) + s.v[(size_t)bt * s.n + j]) / s.eps);
+}
+// sum of x * y in double (earth_movers_distance's (P * M).sum(), :156): per-block partials, folded by the host
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot_partial(const T* __restrict__ x, const T* __restrict__ y, size_t count, double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) acc += (double)(T)(x[i] * y[i]);
+    acc = blk_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+}  // namespace pcu

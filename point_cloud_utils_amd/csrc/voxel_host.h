@@ -215,3 +215,102 @@ static int dedup_impl(pcu_hip_ctx* c, const T* pts, int64_t n, double epsilon, T
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
+
+// ---------------------------------------------------------------------------------------------------- pairwise distances / Sinkhorn (8f-3)
+template <typename T>
+static int pairwise_impl(pcu_hip_ctx* c, const T* a, const T* b, int64_t nb, int64_t m, int64_t n, int64_t d, double p_norm, T* out, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (nb <= 0 || m <= 0 || n <= 0 || d <= 0) return 0;            // empty result
+    if (nb > 65535) return fail(PCU_HIP_ERR_INVALID, "more than 65535 batches are not supported");
+    if (m > 0x7fffffffll || n > 0x7fffffffll || d > 0x7fffffffll) return fail(PCU_HIP_ERR_INVALID, "dimension too large");
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    const size_t na = (size_t)nb * m * d, nbb = (size_t)nb * n * d, no = (size_t)nb * m * n;
+    if (ctx_begin(c, on_dev ? 4096 : align_up(na * sizeof(T), 256) + align_up(nbb * sizeof(T), 256) + align_up(no * sizeof(T), 256) + 4096)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T *da, *db;
+        if ((rc = stage_any(ar, a, na, on_dev, s, &da)) || (rc = stage_any(ar, b, nbb, on_dev, s, &db))) break;
+        T* dout = out;
+        if (!on_dev && (rc = aalloc(ar, &dout, no))) break;
+        const int pc = std::isnan(p_norm) ? P_TWO : pcode_of(p_norm);                 // ord=None: the 2-norm
+        hipLaunchKernelGGL((k_pairwise<T>), dim3((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4), (unsigned)nb), dim3(256), 0, s, da, db, (int)m, (int)n, (int)d, pc, p_norm, dout);
+        HIP_TRY(hipGetLastError());
+        if (!on_dev) HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename T>
+static int sinkhorn_impl(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int64_t nb, int64_t m, int64_t n, double eps, int max_iters, double stop_thresh,
+                         T* out_P, int* out_iters, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    if (nb <= 0 || m <= 0 || n <= 0) { if (out_iters) *out_iters = 0; return 0; }
+    if (nb > 65535 || m > 0x7fffffffll || n > 0x7fffffffll) return fail(PCU_HIP_ERR_INVALID, "problem too large: at most 65535 batches, 2^31-1 samples per measure");
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    const size_t nM = (size_t)nb * m * n, nu = (size_t)nb * m, nv = (size_t)nb * n;
+    size_t need = 2 * (align_up(nu * sizeof(T), 256) + align_up(nv * sizeof(T), 256)) + 8192;
+    if (!on_dev) need += 2 * align_up(nM * sizeof(T), 256) + align_up(nu * sizeof(T), 256) + align_up(nv * sizeof(T), 256);
+    if (ctx_begin(c, need)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        SinkArgs<T> k;
+        if ((rc = stage_any(ar, a, nu, on_dev, s, &k.a)) || (rc = stage_any(ar, b, nv, on_dev, s, &k.b)) || (rc = stage_any(ar, M, nM, on_dev, s, &k.M))) break;
+        T* dP = out_P;
+        if (!on_dev && (rc = aalloc(ar, &dP, nM))) break;
+        int* flagsd = nullptr;
+        if ((rc = aalloc(ar, &k.u, nu)) || (rc = aalloc(ar, &k.v, nv)) || (rc = aalloc(ar, &k.du, nu)) || (rc = aalloc(ar, &k.dv, nv)) || (rc = aalloc(ar, &flagsd, 16))) break;
+        HIP_TRY(hipMemsetAsync(k.u, 0, nu * sizeof(T), s)); HIP_TRY(hipMemsetAsync(k.v, 0, nv * sizeof(T), s));      // u = zeros_like(a), v = zeros_like(b) (:99-100)
+        HIP_TRY(hipMemsetAsync(flagsd, 0, 16 * sizeof(int), s));
+        k.nb = (int)nb; k.m = (int)m; k.n = (int)n; k.eps = (T)eps; k.done = flagsd;
+        int host_flags[2] = {0, 0};
+        for (int it = 0; it < max_iters; ++it) {
+            hipLaunchKernelGGL((k_sink_rows<T>), dim3((unsigned)m, (unsigned)nb), dim3(256), 0, s, k);
+            hipLaunchKernelGGL((k_sink_cols<T>), dim3((unsigned)((n + 31) / 32), (unsigned)nb), dim3(1024), 0, s, k);
+            hipLaunchKernelGGL((k_sink_check<T>), dim3(1), dim3(1024), 0, s, k, (T)stop_thresh, flagsd + 1);
+            if ((it & 7) == 7) {             // every 8 iterations: has the stopping rule fired? (later launches are no-ops once it has)
+                HIP_TRY(hipMemcpyAsync(host_flags, flagsd, sizeof host_flags, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (host_flags[0]) break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((k_sink_plan<T>), dim3((unsigned)((n + 255) / 256), (unsigned)m, (unsigned)nb), dim3(256), 0, s, k, dP);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_flags, flagsd, sizeof host_flags, hipMemcpyDeviceToHost, s));
+        if (!on_dev) HIP_TRY(hipMemcpyAsync(out_P, dP, nM * sizeof(T), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (out_iters) *out_iters = host_flags[1];
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename T>
+static int dot_impl(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, double* out, unsigned flags, void* stream) {
+    if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
+    *out = 0.0;
+    if (count <= 0) return 0;
+    const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
+    hipStream_t s = pick_stream(c, flags, stream);
+    constexpr int kParts = 1024;
+    if (ctx_begin(c, (on_dev ? 0 : 2 * align_up((size_t)count * sizeof(T), 256)) + 65536)) return PCU_HIP_ERR_RUNTIME;
+    Arena ar{c};
+    int rc = 0;
+    do {
+        const T *dx, *dy; double* part = nullptr;
+        if ((rc = stage_any(ar, x, (size_t)count, on_dev, s, &dx)) || (rc = stage_any(ar, y, (size_t)count, on_dev, s, &dy)) || (rc = aalloc(ar, &part, kParts))) break;
+        hipLaunchKernelGGL((k_dot_partial<T>), dim3(kParts), dim3(256), 0, s, dx, dy, (size_t)count, part);
+        HIP_TRY(hipGetLastError());
+        double h[kParts];
+        HIP_TRY(hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        double r = 0; for (int i = 0; i < kParts; ++i) r += h[i];
+        *out = r;
+    } while (0);
+    ctx_end(c);
+    return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}

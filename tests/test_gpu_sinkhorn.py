@@ -1,0 +1,79 @@
+"""GPU parity tests (-m gpu) of pairwise_distances / sinkhorn / earth_movers_distance against
+(1) tests/golden/sinkhorn.npz, generated from the reference's own numpy module by tests/golden/make_golden_sinkhorn.py, and
+(2) the numpy restatement oracle.sinkhorn on larger seeded problems. Tolerances (the operation order per element is the
+reference's; only the order of the sums differs): pairwise 1e-6 / 1e-13 relative; Sinkhorn plan 2e-4 / 1e-9 relative to the
+plan's largest entry (float32 / float64) -- the iteration is a contraction, rounding differences do not grow."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sinkhorn.npz")
+
+
+@pytest.fixture(scope="module")
+def pcu():
+    import point_cloud_utils_amd as m
+    from point_cloud_utils_amd import _lib
+    assert _lib.device_count() > 0
+    return m
+
+
+def _close(x, x0, rtol):
+    scale = np.abs(x0).max()
+    assert x.shape == x0.shape and x.dtype == x0.dtype
+    assert np.abs(x.astype(np.float64) - x0.astype(np.float64)).max() <= rtol * scale, float(np.abs(x.astype(np.float64) - x0).max() / scale)
+
+
+def test_golden_from_the_reference_module(pcu):
+    g = np.load(GOLD)
+    for tag, rt_m, rt_p in (("f32", 2e-6, 2e-4), ("f64", 1e-13, 1e-9)):
+        a, b = g[f"a_{tag}"], g[f"b_{tag}"]
+        for p in (None, 1, np.inf, 3):
+            _close(pcu.pairwise_distances(a, b, p), g[f"M_{tag}_p{p}"], rt_m if p != 3 else max(rt_m, 1e-6))
+        M = g[f"M_{tag}_pNone"]
+        dt = a.dtype.type
+        wa = np.full(96, 1.0 / 96, dt); wb = np.full(80, 1.0 / 80, dt)
+        _close(pcu.sinkhorn(wa, wb, M, eps=1e-2, max_iters=60), g[f"P_{tag}"], rt_p)
+        Pb = pcu.sinkhorn(g[f"wab_{tag}"], g[f"wbb_{tag}"], g[f"Mb_{tag}"], eps=5e-2, max_iters=100, stop_thresh=1e-4)
+        _close(Pb, g[f"Pb_{tag}"], rt_p)
+        _close(pcu.pairwise_distances(g[f"ab_{tag}"], g[f"bb_{tag}"]), g[f"Mb_{tag}"], rt_m)
+    emd, P = pcu.earth_movers_distance(g["emd_p"], g["emd_q"], eps=1e-2)
+    assert abs(float(emd) - float(g["emd"])) <= 1e-9 * float(g["emd"])
+    _close(P, g["emd_P"], 1e-9)
+    with pytest.raises(ValueError, match="must have the same dtype"):
+        pcu.earth_movers_distance(g["emd_p"].astype(np.float32), g["emd_q"].astype(np.float32))       # as in the reference: float64 weights vs float32 M
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sinkhorn_vs_restatement_larger(pcu, dtype):
+    """The reference's test bodies (tests/test_examples.py:289-335) at larger sizes, against the numpy restatement."""
+    rng = np.random.default_rng(7)
+    a = rng.random((1500, 3)).astype(dtype); b = rng.random((1200, 3)).astype(dtype)
+    M = pcu.pairwise_distances(a, b)
+    _close(M, oracle.pairwise_distances(a, b), 2e-6 if dtype == np.float32 else 1e-13)
+    w_a = np.ones(a.shape[0], dtype) / dtype(a.shape[0]); w_b = np.ones(b.shape[0], dtype) / dtype(b.shape[0])
+    P = pcu.sinkhorn(w_a, w_b, M, eps=1e-3)
+    P0, it0 = oracle.sinkhorn(w_a, w_b, M, eps=1e-3)
+    assert abs(pcu.sinkhorn.last_iterations - it0) <= 1
+    if pcu.sinkhorn.last_iterations == it0:
+        _close(P, P0, 5e-4 if dtype == np.float32 else 1e-8)
+    # the plan's marginals are the weights (a property of the fixed point, checked loosely: 100 iterations at eps = 1e-3)
+    assert np.abs(P.sum(0) - w_b).max() < 5e-2 * w_b[0]             # the column marginal is enforced by the last (v) update
+    d = (M * P).sum()
+    assert 0 < d < 1
+    # batched
+    ab = rng.random((4, 300, 3)).astype(dtype); bb = rng.random((4, 260, 3)).astype(dtype)
+    Mb = pcu.pairwise_distances(ab, bb)
+    wa = np.ones((4, 300), dtype) / dtype(300); wb = np.ones((4, 260), dtype) / dtype(260)
+    Pb = pcu.sinkhorn(wa, wb, Mb, eps=1e-2, max_iters=50)
+    Pb0, _ = oracle.sinkhorn(wa, wb, Mb, eps=1e-2, max_iters=50)
+    _close(Pb, Pb0, 5e-4 if dtype == np.float32 else 1e-8)
+    with pytest.raises(ValueError, match="Got unexpected shape for tensor a"):
+        pcu.sinkhorn(wa[:, :10], wb, Mb, eps=1e-2)
+    import torch
+    Pt = pcu.sinkhorn(torch.from_numpy(wa).cuda(), torch.from_numpy(wb).cuda(), torch.from_numpy(Mb).cuda(), eps=1e-2, max_iters=50)
+    assert Pt.is_cuda and np.array_equal(Pt.cpu().numpy(), Pb)                 # device-resident inputs: same kernels, same bits

@@ -10,7 +10,7 @@ import oracle
 from conftest import cloud
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith("metrics.npz"))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith(("metrics.npz", "sinkhorn.npz")))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
@@ -126,3 +126,29 @@ def test_oracle_voxel_and_dedup_restatements():
     assert len(u) == 100 and np.array_equal(x[svi], u) and np.array_equal(u[svj], x) and np.all(svi < 100)
     assert np.array_equal(oracle.deduplicate_point_cloud(np.array([[0.5, 1.5, -0.5], [2.5, -1.5, 0.49999997]], np.float32), 1.0)[0],
                           np.array([[0.5, 1.5, -0.5], [2.5, -1.5, 0.49999997]], np.float32)[[0, 1]])
+
+
+def test_oracle_sinkhorn_pinned_to_reference_module_and_golden():
+    """The numpy restatement of point_cloud_utils/_sinkhorn.py against tests/golden/sinkhorn.npz (generated from the reference's
+    own module) and, where /root/reference exists, against that module itself on fresh inputs: bit-equal (same numpy calls)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sinkhorn.npz"))
+    for tag in ("f32", "f64"):
+        a, b = g[f"a_{tag}"], g[f"b_{tag}"]
+        for p in (None, 1, np.inf, 3):
+            assert np.array_equal(oracle.pairwise_distances(a, b, p), g[f"M_{tag}_p{p}"])
+        dt = a.dtype.type
+        P, _ = oracle.sinkhorn(np.full(96, 1.0 / 96, dt), np.full(80, 1.0 / 80, dt), g[f"M_{tag}_pNone"], eps=1e-2, max_iters=60)
+        assert np.array_equal(P, g[f"P_{tag}"])
+        Pb, _ = oracle.sinkhorn(g[f"wab_{tag}"], g[f"wbb_{tag}"], g[f"Mb_{tag}"], eps=5e-2, max_iters=100, stop_thresh=1e-4)
+        assert np.array_equal(Pb, g[f"Pb_{tag}"])
+    emd, P = oracle.earth_movers_distance(g["emd_p"], g["emd_q"], eps=1e-2)
+    assert emd == g["emd"] and np.array_equal(P, g["emd_P"])
+    ref = oracle.reference_sinkhorn_module()
+    if ref is not None:
+        rng = np.random.default_rng(5)
+        x = rng.random((2, 30, 4)).astype(np.float32); y = rng.random((2, 25, 4)).astype(np.float32)
+        M = ref.pairwise_distances(x, y, 2)
+        assert np.array_equal(M, oracle.pairwise_distances(x, y, 2))
+        wa = np.full((2, 30), 1 / 30, np.float32); wb = np.full((2, 25), 1 / 25, np.float32)
+        assert np.array_equal(ref.sinkhorn(wa, wb, M, 1e-2), oracle.sinkhorn(wa, wb, M, 1e-2)[0])
