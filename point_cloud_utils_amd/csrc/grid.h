@@ -193,7 +193,7 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
     }
     gp->ncells = G[0] * G[1] * G[2];
     for (int j = 0; j < 3; ++j) gp->org[j] = gp->gmin[j];
-    gp->sumsq = 0ull; gp->closed = 0;
+    gp->sumsq = 0ull; gp->closed = 0; gp->has_large = 0;
 }
 template <typename T>
 struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; double h_want; };
@@ -600,7 +600,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
         unsigned run = 0; unsigned long long Q = 0;
         for (int w = 0; w < kSortThreads / 64; ++w) { const unsigned t = s_w[w]; s_w[w] = run; run += t; Q += s_q[w]; }
         if (Q) atomicAdd(&gp->sumsq, Q);
-        if (large) large_list[atomicAdd(n_large, 1u)] = (unsigned)b;
+        if (large) { large_list[atomicAdd(n_large, 1u)] = (unsigned)b; gp->has_large = 1; }
         if (b == NB - 1) cell_start[g.ncells] = e;
     }
     __syncthreads();
@@ -827,7 +827,7 @@ __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, 
         gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
     }
     gp->ncells = G[0] * G[1] * G[2];
-    gp->sumsq = 0ull; gp->closed = closed;
+    gp->sumsq = 0ull; gp->closed = closed; gp->has_large = 0;
 }
 
 // Heavy part of an indexed cloud: bounding box (+1 cell) and number of the points that sit in cells holding more than

@@ -245,6 +245,9 @@ static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipSt
     if (!ua && !ub) return;
     const LargeJob<T> ja = large_job(ua ? a : *b), jb = large_job(ua && ub ? *b : (ua ? a : *b));
     hipLaunchKernelGGL(k_bucket_large<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, ja, jb, (ua && ub) ? 2 : 1);
+    // every record is placed now: searches may use the index (GridParams::has_large)
+    if (ua) (void)hipMemsetAsync(reinterpret_cast<char*>(a.gp) + offsetof(GridParams<T>, has_large), 0, sizeof(int), s);
+    if (ub) (void)hipMemsetAsync(reinterpret_cast<char*>(b->gp) + offsetof(GridParams<T>, has_large), 0, sizeof(int), s);
 }
 // Enqueue the build of one or two indexes on `s`: every pass is ONE launch serving both clouds (grid.h: blocks [0, nb0)
 // work on the first, the rest on the second). No memset, no host synchronisation. zero2: a small region (the call's
@@ -437,7 +440,8 @@ static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, cons
 }
 
 // Per-direction lists and counters. Counter slots:
-enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_SKEW = 6, C_X0 = 7, C_X1 = 8, C_N = 12 };
+enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_SKEW = 6, C_X0 = 7, C_X1 = 8, C_LARGE = 9, C_N = 12 };
+static_assert(C_LARGE - C_SKEW == kLargeFlag, "search.h addresses the large-bucket flag relative to the skew flag");
 template <typename T>
 struct SearchScratch {
     int *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *t1 = nullptr, *tt = nullptr, *x0 = nullptr, *x1 = nullptr;
@@ -485,6 +489,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
     a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
+    a.qgp = j.qidx.gp;
     a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k;
@@ -745,12 +750,23 @@ template <typename T>
 static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc) {
     // hc: host copy of j.sc.counters, read back by the caller together with the call's scalar results
     // (one D2H copy + one stream sync for the whole call in the common case)
-    int hc_redo[C_N];
+    int hc_redo[C_N], hc_large[C_N];
     bool redone = false;
+    if (hc[C_LARGE]) {
+        // Over-full buckets of a bucketed index were still unplaced (their placement, k_bucket_large, is only launched on demand):
+        // every pass gave up at once. Place them -- for the query cloud and the dataset -- and run the passes again.
+        index_large_pass<T>(j.qidx, &j.ridx, s);
+        if (search_enqueue(c, s, j, st)) return -1;
+        HIP_TRY(hipMemcpyAsync(hc_large, j.sc.counters, sizeof hc_large, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        hc = hc_large; redone = true;
+    }
     if (hc[C_SKEW]) {
         // The dataset grid is badly unbalanced (clusters, blobs, a far outlier inflating the bbox): every pass gave up
         // at once. Refit: same cell count over the core range of the cloud (replaces `ridx`), then up to two finer
         // grids sized by how unbalanced the previous one still is; the passes then run finest grid first.
+        index_large_pass<T>(j.qidx, &j.ridx, s);        // (the balance check comes first in the kernels: unplaced over-full buckets
+                                                        // of the query index would stop the passes below as well)
         QuantState<T>* qs = nullptr;
         if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
         GridIndex<T> base, sub1, sub2;
@@ -846,7 +862,8 @@ static int unpermute_enqueue(hipStream_t s, const SearchJob<T>& j, T* dst_d, lon
                              const ResultBlock* rb = nullptr, int* host_block = nullptr, unsigned seq = 0) {
     const long long n_elems = (long long)j.qidx.n * j.k;
     hipLaunchKernelGGL(k_unpermute<T>, dim3((unsigned)((n_elems + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       j.qidx.pos_of, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k, reinterpret_cast<const int*>(rb), host_block, seq);
+                       j.qidx.pos_of, j.out_d, j.out_i, dst_d, dst_i, n_elems, j.k, reinterpret_cast<const int*>(rb), host_block, seq,
+                       j.sc.counters + C_SKEW);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1010,8 +1027,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         }
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break; }
-        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, false, rb, (int)(sizeof(ResultBlock) / 4)))) break;
+        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/true, rb, (int)(sizeof(ResultBlock) / 4)))) break; }
+        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, true, rb, (int)(sizeof(ResultBlock) / 4)))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
@@ -1139,8 +1156,9 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     tm.mark(0);
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, false, P.cb, (int)(sizeof(CallBlock) / 4))) return -1; }
-    else if (index_build(ix, P.dx, occ, s, false, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2)) return -1;
+    // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/true, P.cb, (int)(sizeof(CallBlock) / 4))) return -1; }
+    else if (index_build(ix, P.dx, occ, s, true, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2, true)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
@@ -1174,7 +1192,7 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
 template <typename T>
 static bool fused_ok(const PairState<T>& P, const ResultBlock& h, bool tie_matters) {
     for (int d = 0; d < (P.two ? 2 : 1); ++d) {
-        if (h.counters[d][C_SKEW] || h.counters[d][C_U2] > 0) return false;
+        if (h.counters[d][C_SKEW] || h.counters[d][C_LARGE] || h.counters[d][C_U2] > 0) return false;
         if (tie_matters && P.fuse == FUSE_ARGMAX && h.pad[2 + d]) return false;
     }
     return true;
@@ -1383,7 +1401,8 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
                 if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
                 // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
-                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx}, sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby};
+                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx, P.xy.sc.counters + C_SKEW},
+                                   sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby, P.yx.sc.counters + C_SKEW};
                 hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
                                    reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
                 HIP_TRY(hipGetLastError());

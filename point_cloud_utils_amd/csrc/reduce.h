@@ -232,7 +232,8 @@ enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
 // both searches + these sums) into pinned host memory, so the call needs no separate final-sum launches and no
 // device-to-host copy kernel behind them.
 template <typename T>
-struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; const T* d; int n; int nb; };
+struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; const T* d; int n; int nb;
+                   const int* giveup; };      // the direction's skew / unplaced-buckets flags: no rows exist (yet) when one is set
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, const PnormSide<T> s1, int pcode, double p, double* partial,
@@ -241,12 +242,14 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
     const PnormSide<T>& sd = second ? s1 : s0;
     const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
     double s = 0;
-    const int n_vec = pcode == P_TWO ? (sd.n & ~3) : 0;       // p = 2: the distances themselves, four per 16/32-byte load
+    const bool skip = sd.giveup && (sd.giveup[0] | sd.giveup[3]);      // ([3]: kLargeFlag of search.h)
+    const int n_all = skip ? 0 : sd.n;
+    const int n_vec = pcode == P_TWO ? (n_all & ~3) : 0;       // p = 2: the distances themselves, four per 16/32-byte load
     for (int i = 4 * (bid * kBlock + (int)threadIdx.x); i < n_vec; i += 4 * sd.nb * kBlock) {
         const T v0 = sd.d[i], v1 = sd.d[i + 1], v2 = sd.d[i + 2], v3 = sd.d[i + 3];
         s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
     }
-    for (int i = n_vec + bid * kBlock + (int)threadIdx.x; i < sd.n; i += sd.nb * kBlock) {
+    for (int i = n_vec + bid * kBlock + (int)threadIdx.x; i < n_all; i += sd.nb * kBlock) {
         T v;
         if (pcode == P_TWO) {
             v = sd.d[i];

@@ -48,6 +48,9 @@ struct SearchArgs {
                                     // must not turn a wave into a millisecond-long pole
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then refits the dataset grid (pcu_hip.hip, search_finish)
+    const GridParams<T>* qgp;       // grid of the QUERY cloud: a pass gives up (flag word skew_flag[kLargeFlag]) when either cloud's bucketed
+                                    // index still has unplaced over-full buckets (GridParams::has_large); the host then runs
+                                    // k_bucket_large and repeats the pass -- the common case saves that launch
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
     int row_out;                    // 1: result row of a query goes to its ORIGINAL row (k >= 4: rows are >= 48 B, scattering whole
@@ -65,6 +68,8 @@ struct SearchArgs {
     // FUSE_ARGMAX one partial per wave in f_wave_v / f_wave_k[wave]. k_fuse_tail (reduce.h) folds everything.
     unsigned long long* f_limbs; double* f_special; T* f_wave_v; long long* f_wave_k;
 };
+
+constexpr int kLargeFlag = 3;      // counters[C_LARGE] relative to counters[C_SKEW] (pcu_hip.hip)
 
 // Append `value` for lanes with `flag` set; one atomic per wave.
 __device__ __forceinline__ void wave_append(bool flag, int value, int* list, int* counter) {
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
 
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
@@ -397,6 +403,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -626,6 +633,7 @@ __global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
+    if (g.has_large | a.qgp->has_large) { if (t0 == 0 && lane == 0) a.skew_flag[kLargeFlag] = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -738,10 +746,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     const int* const c10 = a1.qcount_dev ? a1.qcount_dev : a1.skew_flag; const int* const c11 = a1.qlist2 ? a1.qcount2_dev : a1.skew_flag;
     const int v00 = *c00, v01 = *c01, v10 = *c10, v11 = *c11;
     const unsigned long long ss0 = a0.gp->sumsq, ss1 = a1.gp->sumsq;
+    const int hl0 = a0.gp->has_large | a0.qgp->has_large, hl1 = a1.gp->has_large | a1.qgp->has_large;
     int total0 = (a0.qcount_dev ? v00 : a0.nq) + (a0.qlist2 ? v01 : 0);
     int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
     if (a0.skew_limit > 0.f && (float)ss0 > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
     if (njobs > 1 && a1.skew_limit > 0.f && (float)ss1 > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
+    if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = 1; total0 = 0; }
+    if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = 1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
         const bool job1 = wg >= total0;
         const SearchArgs<T>& a = job1 ? a1 : a0;
@@ -881,7 +892,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict__ pos_of, const T* __restrict__ res_d,
                                                       const long long* __restrict__ res_i, T* __restrict__ out_d,
                                                       long long* __restrict__ out_i, long long n_elems, int k,
-                                                      const int* __restrict__ result_block, int* host_block, unsigned seq) {
+                                                      const int* __restrict__ result_block, int* host_block, unsigned seq, const int* __restrict__ giveup) {
     // (block 0's first wave also hands the call's result block -- the search counters, final by now -- to pinned host
     // memory, sequence word last: see k_pnorm_pair)
     if (host_block && blockIdx.x == 0 && threadIdx.x < 64) {
@@ -891,6 +902,9 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict
     }
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n_elems) return;
+    // (giveup: the search's skew / unplaced-buckets flags. When the passes gave up there are no rows yet, and pos_of may be
+    // incomplete -- the restore is repeated after the host has dealt with it)
+    if (giveup && (giveup[0] | giveup[kLargeFlag])) return;
     const long long i = t / k; const int j = (int)(t - i * k);
     const size_t src = (size_t)pos_of[i] * (size_t)k + j;
     if (out_d) out_d[t] = res_d[src];
