@@ -109,8 +109,8 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
         const int j = threadIdx.x;
         T a = s_lo[0][j], b = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
-        partial[bid * 6 + j] = a;
-        partial[bid * 6 + 3 + j] = b;
+        publish(&partial[bid * 6 + j], a);              // (agent-scope stores: k_bbox_grid's last block reads them in the same launch)
+        publish(&partial[bid * 6 + 3 + j], b);
     }
 }
 
@@ -138,7 +138,7 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
         for (int b = threadIdx.x; b < nparts; b += kBlock)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T a = partial[b * 6 + j], c = partial[b * 6 + 3 + j];
+                T a = peek(&partial[b * 6 + j]), c = peek(&partial[b * 6 + 3 + j]);
                 lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
             }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -243,6 +243,26 @@ __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int
         if (s_key[k] != 0xffffffffu) s_base[k] = atomicAdd(&counts[s_key[k]], s_cnt[k]);
     __syncthreads();
     if (i < n) rank[i] = c != 0xffffffffu ? s_base[slot] + lr : 0u;
+}
+
+// k_bbox_partial + k_make_grid in ONE launch (opt-in, PCU_HIP_FUSED_GRID=1; measured slower than the two launches, see
+// index_build_pair): the block of a side that takes the side's last ticket folds the partials and lays out the grid (publish /
+// peek / relaxed ticket, no __threadfence). tickets: two zero-initialised words owned by the context, reset by the folding block.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bbox_grid(const BboxSide<T> a0, const BboxSide<T> a1, int nb0, const GridSide<T> g0, const GridSide<T> g1, unsigned* tickets) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BboxSide<T>& a = second ? a1 : a0;
+    const int nblk = second ? (int)gridDim.x - nb0 : nb0;
+    bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, nblk);
+    __shared__ bool s_last;
+    wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = take_ticket(&tickets[second ? 1 : 0], (unsigned)nblk);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) tickets[second ? 1 : 0] = 0u;
+    const GridSide<T>& g = second ? g1 : g0;
+    make_grid_body<T>(g.gp, g.partial, g.nparts, g.n, g.occupancy, g.max_cells, g.sentinel, g.h_want);
 }
 
 // ---- exclusive scan over `counts[0..m)` in place; counts[m] receives the total -------------------------

@@ -67,6 +67,7 @@ struct pcu_hip_ctx {
     bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
+    unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;
@@ -259,14 +260,22 @@ static BucketSide<T> bucket_side(const GridIndex<T>& g, const T* pts) {
 }
 template <typename T>
 static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex<T>* b, const T* pb, double occb, hipStream_t s,
-                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
+                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, unsigned* tickets = nullptr) {
     {
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
-        hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
         const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n, a.h_want};
         const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n, b->h_want} : g0;
-        hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
+        // One launch for both (k_bbox_grid, last block lays out the grid) is opt-in: measured on MI355X at 2 x 1M points it takes
+        // 16.7 us against 8.1 + 4.9 us for the two launches (the folding block's chain of round trips -- ticket, 512 partials, the
+        // serial layout -- is longer than a launch boundary), step 0.187 vs 0.184 ms.
+        static const bool fused = getenv("PCU_HIP_FUSED_GRID") != nullptr;
+        if (tickets && fused) {
+            hipLaunchKernelGGL(k_bbox_grid<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks, g0, g1, tickets);
+        } else {
+            hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
+            hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
+        }
     }
     // bucketed sides share their launches; a side too small / too coarse for buckets takes the atomic passes
     const GridIndex<T>* bs[2]; const T* bp[2]; int nbs = 0;
@@ -320,8 +329,9 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     return 0;
 }
 template <typename T>
-static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0) {
-    return index_build_pair<T>(g, d_pts, occ, nullptr, nullptr, 0.0, s, defer_large, zero2, n_zero2);
+static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0,
+                       unsigned* tickets = nullptr) {
+    return index_build_pair<T>(g, d_pts, occ, nullptr, nullptr, 0.0, s, defer_large, zero2, n_zero2, tickets);
 }
 
 // Refitted grids for unbalanced clouds (grid.h): core range of the cloud by three zooming histogram rounds, then
@@ -1027,8 +1037,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         }
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/true, rb, (int)(sizeof(ResultBlock) / 4)))) break; }
-        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, true, rb, (int)(sizeof(ResultBlock) / 4)))) break;
+        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/true, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break; }
+        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, true, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
@@ -1157,7 +1167,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/true, P.cb, (int)(sizeof(CallBlock) / 4))) return -1; }
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/true, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
     else if (index_build(ix, P.dx, occ, s, true, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2, true)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
@@ -1693,6 +1703,8 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into it
     memset(c->h_pinned, 0, 64 * sizeof(int));
+    HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
+    HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
     *out_ctx = c;
     return 0;
 }
@@ -1705,6 +1717,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     c->lanes.clear();
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     if (c->aux) (void)hipFree(c->aux);
+    if (c->tickets) (void)hipFree(c->tickets);
     if (c->arena) (void)hipFree(c->arena);
     kd_graph_drop(c);
     if (c->kd_ws) (void)hipFree(c->kd_ws);
