@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per cloud (default: the headline 1M)")
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5", "normals", "morton", "voxel", "sinkhorn"])
     ap.add_argument("--pairs", type=int, default=32, help="c4: pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -283,6 +283,67 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
                 h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
                 ok &= tuple(rows[p]) == tuple(float(v) for v in h0)
             return {"pairs_checked": min(2, npairs), "tuples_equal": bool(ok)}
+    elif cfg == "normals":          # 1M-point sheet, k = 16
+        n, k = 1_000_000, 16
+        rng = np.random.default_rng(9 + rank)
+        xy = rng.random((n, 2)) * 2 - 1
+        p = np.ascontiguousarray(np.concatenate([xy, (0.3 * np.sin(3 * xy[:, :1]) * np.cos(2 * xy[:, 1:2]))], 1).astype(np.float32))
+        tp = torch.from_numpy(p).to(dev)
+        step = lambda: pcu.estimate_point_cloud_normals_knn(tp, k)
+        units, alg = n, n * (12 + 12 + 8)
+        name = f"estimate_point_cloud_normals_knn k={k}, {n} fp32 points"
+        def check():
+            sel = np.random.default_rng(0).choice(n, 20000, replace=False)
+            idx, nrm = step()
+            _, c = oracle.knn(p[sel], p, k, True, kind=kind)
+            a = (p[c] - p[sel][:, None, :]).astype(np.float64)
+            t0 = time.perf_counter(); _, sv, vt = np.linalg.svd(a, full_matrices=False); t_svd = time.perf_counter() - t0
+            good = (sv[:, 1] - sv[:, 2]) / sv[:, 0] > 1e-2
+            dot = np.abs(np.einsum("ij,ij->i", nrm.cpu().numpy()[sel].astype(np.float64), vt[:, 2, :]))
+            return {"points_checked": int(good.sum()), "max_1_minus_abs_dot": float((1 - dot[good]).max()), "tol": 1e-6,
+                    "cpu_numpy_svd_points_per_s": 20000 / t_svd}
+    elif cfg == "morton":           # element-wise integer kernel, the HBM-bound extreme
+        n = 16_000_000
+        pts = np.random.default_rng(rank).integers(-(1 << 20), 1 << 20, (n, 3)).astype(np.int32)
+        tp = torch.from_numpy(pts).to(dev)
+        step = lambda: pcu.morton_encode(tp)
+        units, alg = n, n * 20
+        name = f"morton_encode, {n} int32 points"
+        def check():
+            c = step().cpu().numpy().view(np.uint64)
+            mk = "ref" if oracle.have_ref_morton() else "port"
+            t0 = time.perf_counter(); c0 = oracle.morton_encode(pts[:2_000_000], mk); t_cpu = time.perf_counter() - t0
+            return {"codes_equal": bool(np.array_equal(c[:2_000_000], c0)), "checker": mk, "cpu_points_per_s_1core": 2_000_000 / t_cpu}
+    elif cfg == "voxel":
+        n = 1_000_000
+        p = cloud(5 + rank, n, np.float32); tp = torch.from_numpy(p).to(dev)
+        vs = 1.0 / 128.0
+        mb, xb = tuple(np.min(p, 0) - vs / 2), tuple(np.max(p, 0) + vs / 2)
+        step = lambda: pcu.downsample_point_cloud_on_voxel_grid(vs, tp, min_bound=mb, max_bound=xb)
+        units, alg = n, n * 12 + 2_000_000
+        name = f"downsample_point_cloud_on_voxel_grid, {n} fp32 points, voxel 1/128"
+        def check():
+            v = step().cpu().numpy()
+            t0 = time.perf_counter(); v0, _ = oracle.voxel_downsample(p[:200000], None, [vs] * 3, mb); t_cpu = time.perf_counter() - t0
+            v1 = pcu.downsample_point_cloud_on_voxel_grid(vs, p[:200000], min_bound=mb, max_bound=xb)
+            return {"voxels": int(len(v)), "means_bit_equal_on_200k": bool(np.array_equal(v1, v0)), "cpu_points_per_s_1core_python": 200000 / t_cpu}
+    elif cfg == "sinkhorn":         # dense 4096 x 4096 cost matrix, 50 iterations
+        m = n = 4096
+        rng = np.random.default_rng(7 + rank)
+        a = rng.random((m, 3)).astype(np.float32); b = rng.random((n, 3)).astype(np.float32)
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        M = pcu.pairwise_distances(ta, tb)
+        wa = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev); wb = torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev)
+        iters = 50
+        step = lambda: pcu.sinkhorn(wa, wb, M, eps=1e-2, max_iters=iters, stop_thresh=0.0)
+        units, alg = iters * m * n, iters * 2 * m * n * 4 + m * n * 4 * 2
+        name = f"sinkhorn, {m} x {n} fp32 cost matrix, {iters} iterations (unit: matrix elements x iterations)"
+        def check():
+            P = step().cpu().numpy()
+            t0 = time.perf_counter(); P0, _ = oracle.sinkhorn(wa.cpu().numpy()[:1024], wb.cpu().numpy()[:1024], M.cpu().numpy()[:1024, :1024] , 1e-2, 5, 0.0); t_cpu = time.perf_counter() - t0
+            Pfull, it = oracle.sinkhorn(wa.cpu().numpy(), wb.cpu().numpy(), M.cpu().numpy(), 1e-2, iters, 0.0)
+            return {"plan_max_rel_err": float(np.abs(P - Pfull).max() / np.abs(Pfull).max()), "tol": 5e-4,
+                    "cpu_numpy_elements_x_iters_per_s": 5 * 1024 * 1024 / t_cpu}
     else:
         bunny = np.load(os.path.join(ROOT, "tests", "golden", "bunny_v.npy")).astype(np.float64)
         f = np.load(os.path.join(ROOT, "tests", "golden", "bunny_f.npy"))
@@ -315,9 +376,10 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         if not args.no_parity:
             parity = check()
         steps = max(args.steps, 1)
-        out = {"metric": f"query-points/s, {name}", "value": units * world * steps / dt, "unit": "query-points/s", "n_gpus": world,
+        unit = "query-points/s" if cfg in ("c2", "c3", "c4", "c5") else ("elements*iterations/s" if cfg == "sinkhorn" else "points/s")
+        out = {"metric": f"{unit}, {name}", "value": units * world * steps / dt, "unit": unit, "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64" if cfg == "c5" else "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f64" if cfg == "c5" else ("i32" if cfg == "morton" else "f32"), "data": "synthetic",
                "config": {"workload": name + ", inputs resident in HBM", "baseline_config": cfg},
                "roofline": {"bound": "hbm", "achieved": alg / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_step": alg,

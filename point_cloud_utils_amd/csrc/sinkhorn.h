@@ -94,17 +94,20 @@ __global__ __launch_bounds__(256) void k_sink_rows(const SinkArgs<T> s) {
         s.du[o] = d < 0 ? -d : d; s.u[o] = un;
     }
 }
-// v update (:116-117): a block owns 32 consecutive columns, 32 thread rows stride over i. The column sums use a streaming
-// log-sum-exp (running maximum, rescaled sum), so M is read once; the 32 partial (max, sum) pairs of a column are merged in LDS.
+// v update (:116-117): a block owns 32 consecutive columns of one SLAB of rows (grid.z slabs, so that even a single batch of a few
+// thousand columns fills the chip); its 32 thread rows stride over the slab's rows. The column sums use a streaming
+// log-sum-exp (running maximum, rescaled sum), so M is read once; the 32 partial (max, sum) pairs of a column are merged in LDS
+// into the slab's partial, and k_sink_cols_finish merges the slabs in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s) {
+__global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s, T* __restrict__ part_mx, T* __restrict__ part_sum, int rows_per_slab) {
     if (*s.done) return;
     __shared__ T s_mx[32][33], s_sum[32][33];
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5, j = blockIdx.x * 32 + c, bt = blockIdx.y;
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5, j = blockIdx.x * 32 + c, bt = blockIdx.y, slab = blockIdx.z;
     const T* Mb = s.M + (size_t)bt * s.m * s.n; const T* u = s.u + (size_t)bt * s.m;
+    const int i0 = slab * rows_per_slab, i1 = min(s.m, i0 + rows_per_slab);
     T mx = -(T)INFINITY, acc = 0;
     if (j < s.n)
-        for (int i = r; i < s.m; i += 32) {
+        for (int i = i0 + r; i < i1; i += 32) {
             const T x = (-Mb[(size_t)i * s.n + j] + u[i]) / s.eps;
             if (x > mx) { acc = acc * exp(mx - x) + (T)1; mx = x; } else acc += exp(x - mx);
         }
@@ -115,12 +118,24 @@ __global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s) {
         for (int k = 1; k < 32; ++k) M2 = s_mx[k][c] > M2 ? s_mx[k][c] : M2;
         T tot = 0;
         for (int k = 0; k < 32; ++k) tot += s_mx[k][c] == -(T)INFINITY ? (T)0 : s_sum[k][c] * exp(s_mx[k][c] - M2);
-        const T lse = log(tot) + M2;
-        const size_t o = (size_t)bt * s.n + j;
-        const T vn = s.eps * (log(s.b[o]) - lse);
-        const T d = s.v[o] - vn;
-        s.dv[o] = d < 0 ? -d : d; s.v[o] = vn;
+        const size_t o = ((size_t)slab * s.nb + bt) * s.n + j;
+        part_mx[o] = M2; part_sum[o] = tot;
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_sink_cols_finish(const SinkArgs<T> s, const T* __restrict__ part_mx, const T* __restrict__ part_sum, int n_slabs) {
+    if (*s.done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x, bt = blockIdx.y;
+    if (j >= s.n) return;
+    const size_t o = (size_t)bt * s.n + j, stride = (size_t)s.nb * s.n;
+    T M2 = part_mx[o];
+    for (int k = 1; k < n_slabs; ++k) { const T v = part_mx[o + k * stride]; M2 = v > M2 ? v : M2; }
+    T tot = 0;
+    for (int k = 0; k < n_slabs; ++k) { const T v = part_mx[o + k * stride]; tot += v == -(T)INFINITY ? (T)0 : part_sum[o + k * stride] * exp(v - M2); }
+    const T lse = log(tot) + M2;
+    const T vn = s.eps * (log(s.b[o]) - lse);
+    const T d = s.v[o] - vn;
+    s.dv[o] = d < 0 ? -d : d; s.v[o] = vn;
 }
 // err_u = max_b sum_i |du| , err_v likewise (:119-120); done when both are below the threshold (:122-123). One block.
 template <typename T>
