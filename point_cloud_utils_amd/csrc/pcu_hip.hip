@@ -68,6 +68,8 @@ struct pcu_hip_ctx {
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
     unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
+    bool eager_large = false;                 // sticky: this context has met clouds with over-full buckets (surfaces, clusters): launch their
+                                              // placement (k_bucket_large) with every build instead of on demand
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;
@@ -766,6 +768,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         // Over-full buckets of a bucketed index were still unplaced (their placement, k_bucket_large, is only launched on demand):
         // every pass gave up at once. Place them -- for the query cloud and the dataset -- and run the passes again.
         index_large_pass<T>(j.qidx, &j.ridx, s);
+        c->eager_large = true;                   // data of this kind will come again (mesh samples: +0.18 ms per call for the round trip)
         if (search_enqueue(c, s, j, st)) return -1;
         HIP_TRY(hipMemcpyAsync(hc_large, j.sc.counters, sizeof hc_large, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -1037,8 +1040,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         }
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/true, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break; }
-        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, true, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
+        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/!c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break; }
+        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
@@ -1167,8 +1170,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/true, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
-    else if (index_build(ix, P.dx, occ, s, true, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2, true)) return -1;
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
+    else if (index_build(ix, P.dx, occ, s, !c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2, !c->eager_large)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));

@@ -30,3 +30,9 @@ if [ -x $ROOT/profiles/calib/calib_gather ]; then
   rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum --output-format csv -d $OUT/${TAG}_calib_tcc -- $C > $OUT/${TAG}_calib_tcc.log 2>&1
 fi
 tail -c 2500 $OUT/${TAG}_bench.json
+# the other BASELINE configs and the widened rows: one bench line each, parity checked inside
+: > $OUT/${TAG}_configs.jsonl
+for c in c2 c3 c4 c5 normals morton voxel sinkhorn; do
+  timeout 300 python $ROOT/bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' >> $OUT/${TAG}_configs.jsonl
+done
+cut -c1-260 $OUT/${TAG}_configs.jsonl

@@ -75,7 +75,10 @@ rep = {"source": f"profiles/{tag}_pmc.txt", "counters_source": f"profiles/{tag}_
        "note": "one launch = both directions of the 1M-vs-1M Chamfer step; calibrated FETCH_SIZE + WRITE_SIZE, see the header of the source file"}
 if dom:
     c = {k: mean(v) for k, v in sq[dom[0]].items()}
-    cyc = c.get("GRBM_GUI_ACTIVE", 0.0)
+    # kernel cycles: SQ_BUSY_CYCLES is summed over the 32 shader engines (each SQ counts the cycles it was busy); GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs and includes the profiler's per-dispatch idle time, so it overstates short kernels
+    cyc = c.get("SQ_BUSY_CYCLES", 0.0) / 32.0 or c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    rep["kernel_cycles"] = cyc
     if cyc and c.get("SQ_INSTS_VALU"):
         # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, wave scheduling); one scalar
         # instruction per cycle per CU
@@ -89,4 +92,7 @@ if dom:
     if c.get("SQ_INST_CYCLES_SALU") and cyc:
         rep["salu_busy_frac"] = c["SQ_INST_CYCLES_SALU"] / (N_CU * cyc)
 json.dump(rep, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+cfg = os.path.join(G, f"{tag}_configs.jsonl")
+if os.path.exists(cfg):
+    open(os.path.join(P, f"{tag}_configs.jsonl"), "w").write(open(cfg).read())
 print(line[:600]); print("\n".join(cal)); print("\n".join(out[4:14])); print(json.dumps(rep, indent=1))
