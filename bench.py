@@ -183,6 +183,14 @@ def main():
             idx_ms += st["ms_index"] / 3; srch_ms += st["ms_search"] / 3; tot_ms += st["ms_total"] / 3
         pcu.set_timing(0)
 
+    # protocol B of SURVEY 8d (diagnostic, OUTSIDE the timed region): end to end numpy -> numpy, i.e. incl. the H2D copies of both
+    # clouds over PCIe and the Python shim; median of 5. Never the reported `value`.
+    e2e_ms = None
+    if rank == 0:
+        ts = []
+        for _ in range(6):
+            t1 = time.perf_counter(); pcu.chamfer_distance(x_h, y_h); ts.append(time.perf_counter() - t1)
+        e2e_ms = float(np.median(ts[1:])) * 1e3
     if rank == 0:
         steps = max(args.steps, 1)
         qpts_per_step = 2 * n * world
@@ -220,6 +228,8 @@ def main():
             "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
                                    "note": "3 extra steps outside the timed region, phase events on"},
             "chamfer": float(results[0]),
+            "end_to_end_numpy": {"ms_per_call": e2e_ms, "value": (2 * n / (e2e_ms * 1e-3)) if e2e_ms else None, "unit": "query-points/s",
+                                 "note": "SURVEY 8d protocol B: host arrays in, Python float out (24 MB H2D inside the call); median of 5, outside the timed region"},
         }
         ref = None
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0, N = 1 only

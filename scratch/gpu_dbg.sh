@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export PYTHONUNBUFFERED=1
 python -c "import torch"
-timeout 120 python scratch/dbg_normals.py 2>&1 | grep -v amdgpu.ids
-timeout 200 python bench.py --config c5 --steps 10 --warmup 3 2>/dev/null | cut -c1-330
+timeout 300 python scratch/skew.py 2>&1 | grep -v amdgpu.ids
+PCU_HIP_DEBUG_SKEW=1 timeout 100 python scratch/skew.py mix_10pct_cluster 2>&1 | grep -v amdgpu.ids | tail -6
