@@ -283,7 +283,7 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         pairs = [(torch.from_numpy(cloud(1000 + 2 * (rank * npairs + p), n, np.float32)).to(dev),
                   torch.from_numpy(cloud(1001 + 2 * (rank * npairs + p), n, np.float32)).to(dev)) for p in range(npairs)]
         from point_cloud_utils_amd import batched
-        step = lambda: batched._map_chunks("hausdorff", lambda p: pairs[p], list(range(npairs)), 4)
+        step = lambda: batched._map_chunks("hausdorff", lambda p: pairs[p], list(range(npairs)), 3)
         units, alg = npairs * 2 * n, npairs * 2 * 3 * 4 * 2 * n
         name = f"hausdorff_distance, {npairs} independent {n}-vs-{n} fp32 pairs per GPU (batch entry point)"
         def check():

@@ -16,6 +16,8 @@
 #include <vector>
 #include <chrono>
 #include <atomic>
+#include <mutex>
+#include <thread>
 
 #include "../../include/pcu_hip.h"
 #include "grid.h"
@@ -72,7 +74,7 @@ struct pcu_hip_ctx {
                                               // placement (k_bucket_large) with every build instead of on demand
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
-    std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;
+    std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 3;   // (measured on 262k-point pairs: 1 / 2 / 3 / 4 / 8 lanes = 106 / 66 / 54 / 64 / 67 us per pair: the host enqueue is the limit from 3 on)
     hipEvent_t batch_ev = nullptr;
 };
 
@@ -1579,29 +1581,58 @@ static int batch_run(pcu_hip_ctx* c, int n_pairs, unsigned flags, void* stream, 
     if (n_pairs < 0) return fail(PCU_HIP_ERR_INVALID, "negative number of pairs");
     if (st) memset(st, 0, sizeof *st);
     if (n_pairs == 0) return 0;
-    const int L = batch_lanes(c, n_pairs, stream, flags);
-    if (L < 0) return PCU_HIP_ERR_RUNTIME;
-    std::vector<PendingPair<T>> pend((size_t)L);
-    std::vector<pcu_hip_stats> lst((size_t)L);
-    std::vector<int> cur((size_t)L, -1);
+    // Optional: several host threads, each enqueueing into lanes of its own (PCU_HIP_BATCH_THREADS, default 1). Measured on 32
+    // pairs of 262k points: what counts is the number of pairs in flight -- 3 is the optimum whether one thread drives them
+    // (55.9 us per pair) or three do (58.8); 4 and more are slower with any thread count (64-78 us).
+    static const int n_threads_env = [] { const char* e = getenv("PCU_HIP_BATCH_THREADS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    const int n_threads = std::max(1, std::min(n_threads_env, n_pairs / 2));
+    const int per_thread = std::max(1, std::min(c->n_lanes_wanted, 16 / n_threads));
+    const int saved_want = c->n_lanes_wanted;
+    c->n_lanes_wanted = per_thread * n_threads;
+    const int L_all = batch_lanes(c, n_pairs, stream, flags);
+    c->n_lanes_wanted = saved_want;
+    if (L_all < 0) return PCU_HIP_ERR_RUNTIME;
     const unsigned lflags = flags & ~(unsigned)(PCU_HIP_STREAM_GIVEN | PCU_HIP_TIME_PHASES | PCU_HIP_TIME_KERNELS);
-    int rc = 0; std::string err;
-    for (int p = 0; p < n_pairs + L; ++p) {
-        const int lane = p % L;
-        if (cur[lane] >= 0) {
-            const int r = end(c->lanes[lane], pend[lane], cur[lane]);
-            if (r && !rc) { rc = r; err = g_err; }
-            stats_add(st, lst[lane]);
-            cur[lane] = -1;
+    std::mutex mu;
+    int rc_all = 0; std::string err_all;
+    auto work = [&](int t) {
+        DeviceGuard dg(c->device);
+        // this thread's lanes and pairs: lanes [l0, l1), pairs t, t + n_threads, ...
+        const int l0 = (int)((long long)L_all * t / n_threads), l1 = (int)((long long)L_all * (t + 1) / n_threads);
+        const int L = l1 - l0;
+        if (L <= 0) return;
+        std::vector<PendingPair<T>> pend((size_t)L);
+        std::vector<pcu_hip_stats> lst((size_t)L);
+        std::vector<int> cur((size_t)L, -1);
+        int rc = 0; std::string err;
+        int k = 0;
+        const int mine = (n_pairs - t + n_threads - 1) / n_threads;
+        for (int it = 0; it < mine + L; ++it) {
+            const int lane = it % L;
+            if (cur[lane] >= 0) {
+                const int r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
+                if (r && !rc) { rc = r; err = g_err; }
+                { std::lock_guard<std::mutex> g(mu); stats_add(st, lst[lane]); }
+                cur[lane] = -1;
+            }
+            if (k < mine && !rc) {
+                const int p = t + k * n_threads; ++k;
+                pend[lane] = PendingPair<T>();
+                const int r = begin(c->lanes[l0 + lane], pend[lane], p, lflags, &lst[lane]);
+                if (r) { rc = r; err = g_err; } else cur[lane] = p;
+            }
         }
-        if (p < n_pairs && !rc) {
-            pend[lane] = PendingPair<T>();
-            const int r = begin(c->lanes[lane], pend[lane], p, lflags, &lst[lane]);
-            if (r) { rc = r; err = g_err; } else cur[lane] = p;
-        }
+        if (rc) { std::lock_guard<std::mutex> g(mu); if (!rc_all) { rc_all = rc; err_all = err; } }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
     }
-    if (rc) g_err = err;
-    return rc;
+    if (rc_all) g_err = err_all;
+    return rc_all;
 }
 
 // ------------------------------------------------------------------------------------------------ persistent index
@@ -1819,7 +1850,7 @@ int pcu_hip_dot_##SUF(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, dou
 PCU_SINK(f32, float) PCU_SINK(f64, double)
 #undef PCU_SINK
 
-int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
+int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 3; return 0; }
 
 int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
 int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
