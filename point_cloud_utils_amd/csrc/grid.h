@@ -17,7 +17,8 @@
 #include "pcu_types.h"
 
 #ifndef PCU_SORT_THREADS
-#define PCU_SORT_THREADS 512      // workgroup size of k_bucket_sort (tuning knob; 1024 measured slower)
+#define PCU_SORT_THREADS 1024     // workgroup size of k_bucket_sort. A/B on MI355X (threads/bucket/stage -> headline, C5 ms):
+                                  // 512/2048/2240 0.188 0.375 | 1024/2048/2240 0.194 0.317 | 1024/4096/4352 0.184 0.340 | 256/1024/1152 0.207
 #endif
 
 namespace pcu {
@@ -402,8 +403,15 @@ constexpr int kBkMaxBuckets = 8192;                 // LDS: 32 KB (count) / 64 K
 constexpr int kBkMaxCellsPerBucket = 4096;
 constexpr int kSortThreads = PCU_SORT_THREADS;
 constexpr int kSortIters = 8;                       // (16 costs 8 more VGPRs: 3 instead of 4 resident blocks per CU)
-constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 4096 points = twice the mean bucket
-constexpr int kStageRecs = 2240;                    // records of a bucket staged in LDS for the coalesced copy-out (mean bucket 2048, sigma 45)
+constexpr unsigned kLargeBucket = kSortThreads * kSortIters;      // 8192 points = twice the mean bucket
+#ifndef PCU_BUCKET_PTS
+#define PCU_BUCKET_PTS 4096
+#endif
+#ifndef PCU_STAGE_RECS
+#define PCU_STAGE_RECS 4352
+#endif
+constexpr int kBucketPts = PCU_BUCKET_PTS;          // expected points per bucket (tuning knob, with PCU_SORT_THREADS and PCU_STAGE_RECS)
+constexpr int kStageRecs = PCU_STAGE_RECS;          // records of a bucket staged in LDS for the coalesced copy-out (mean bucket 4096, sigma 64: the stage holds +4 sigma)
 
 template <typename T> struct RawRec;
 template <> struct RawRec<float>  { typedef unsigned __attribute__((ext_vector_type(4))) type; };
@@ -640,23 +648,19 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
     // puts them into their sorted slots), and leaves as one contiguous, fully coalesced copy: no second pass over `tmp`
     // and whole 128-byte lines instead of one scattered 16-byte store per record. Larger buckets re-read and store directly.
     if (staged) {
-        constexpr int kStageIters = (kStageRecs + kSortThreads - 1) / kSortThreads;       // 5 trips cover the stage
-        static_assert(kStageIters == 5, "unrolled by hand");
+        constexpr int kStageIters = (kStageRecs + kSortThreads - 1) / kSortThreads;       // trips that cover the stage
+        static_assert(kStageIters <= kSortIters, "rr[] holds one rank per trip");
         typedef typename RawRec<T>::type Raw;                 // a record as one vector register tuple (a struct copy goes through scratch)
         Raw* const raw = reinterpret_cast<Raw*>(s_stage);
         const unsigned cnt = e - s;
         const unsigned lastl = cnt ? cnt - 1u : 0u;
-        const Raw m0 = raw[min((unsigned)tid, lastl)];
-        const Raw m1 = raw[min((unsigned)(tid + kSortThreads), lastl)];
-        const Raw m2 = raw[min((unsigned)(tid + 2 * kSortThreads), lastl)];
-        const Raw m3 = raw[min((unsigned)(tid + 3 * kSortThreads), lastl)];
-        const Raw m4 = raw[min((unsigned)(tid + 4 * kSortThreads), lastl)];
+        Raw m[kStageIters];
+#pragma unroll
+        for (int u = 0; u < kStageIters; ++u) m[u] = raw[min((unsigned)(tid + u * kSortThreads), lastl)];
         __syncthreads();
-        if ((unsigned)tid < cnt) raw[s_cnt[rr[0] >> 16] + (rr[0] & 0xffffu)] = m0;
-        if ((unsigned)(tid + kSortThreads) < cnt) raw[s_cnt[rr[1] >> 16] + (rr[1] & 0xffffu)] = m1;
-        if ((unsigned)(tid + 2 * kSortThreads) < cnt) raw[s_cnt[rr[2] >> 16] + (rr[2] & 0xffffu)] = m2;
-        if ((unsigned)(tid + 3 * kSortThreads) < cnt) raw[s_cnt[rr[3] >> 16] + (rr[3] & 0xffffu)] = m3;
-        if ((unsigned)(tid + 4 * kSortThreads) < cnt) raw[s_cnt[rr[4] >> 16] + (rr[4] & 0xffffu)] = m4;
+#pragma unroll
+        for (int u = 0; u < kStageIters; ++u)
+            if ((unsigned)(tid + u * kSortThreads) < cnt) raw[s_cnt[rr[u] >> 16] + (rr[u] & 0xffffu)] = m[u];
         __syncthreads();
         for (unsigned i = tid; i < e - s; i += kSortThreads) {
             const Pt4<T> r = s_stage[i];

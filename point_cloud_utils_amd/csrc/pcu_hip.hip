@@ -197,7 +197,7 @@ static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     if (off || n < 32768 || occ > 64.0) return false;
     const int mc = max_cells_for(n, occ);
     int sh = 5;
-    while (sh < 12 && (double)(2 << sh) * occ <= 2048.0) ++sh;             // largest bucket with <= ~2048 expected points
+    while (sh < 12 && (double)(2 << sh) * occ <= (double)kBucketPts) ++sh;             // largest bucket with <= ~kBucketPts (2048) expected points
     while (sh < 12 && ((mc >> sh) + 1) > kBkMaxBuckets) ++sh;
     const int nb = (mc >> sh) + 1;
     if (nb > kBkMaxBuckets) return false;
