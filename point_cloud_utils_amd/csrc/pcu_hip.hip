@@ -303,14 +303,15 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
             attr_set[sizeof(T) == 4 ? 0 : 1] = true;
         }
-        // the bucket sort is the one pass that does NOT share a launch: its blocks are all resident at once (4 per CU) and
-        // finish in one round per cloud; 2 x 15 us apart against 39 us together (PCU_HIP_PAIR_SORT=1) on MI355X
-        static const bool split_sort = getenv("PCU_HIP_PAIR_SORT") == nullptr;
+        // One launch for both clouds, like the other passes. (With 512-thread blocks / 2048-point buckets the sort was faster as one
+        // launch per cloud -- 2 x 15.6 us against 39 us; with 1024 threads / 4096-point buckets all blocks of both clouds are
+        // resident at once and the shared launch wins: step 0.174 vs 0.186 ms. PCU_HIP_SPLIT_SORT=1 restores the split.)
+        static const bool split_sort = getenv("PCU_HIP_SPLIT_SORT") != nullptr;
         if (split_sort && nbs > 1) {
             hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0), dim3(kSortThreads), lds, s, s0, s0, t0, do_prof ? prof : nullptr, cnt_cap);
             hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t1), dim3(kSortThreads), lds, s, s1, s1, t1, do_prof ? prof : nullptr, cnt_cap);
         } else
-        hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
+            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
         if (do_prof) {
             long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
             const double nb = h[7] > 0 ? (double)h[7] : 1.0;
@@ -420,9 +421,17 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     if (K == 1 && use_gather && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
-        if (a.fuse == FUSE_SUM) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_SUM>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
-        else if (a.fuse == FUSE_ARGMAX) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_ARGMAX>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
-        else hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE_NONE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
+        // PCU_HIP_BAL=1 (float): the balanced variant (search.h: search1_bal_body; item = record << 6 | lane, hence the size limit).
+        // Opt-in: measured on MI355X it runs 7.7 instead of ~20 loop trips per wave and a third fewer gather instructions, but
+        // as many VALU instructions (1344 vs 1260 per wave), and VALU issue is what bounds both: 84-87 us against 82-83 us.
+        static const bool want_bal = getenv("PCU_HIP_BAL") != nullptr;
+        const bool bal = sizeof(T) == 4 && want_bal && a.n_ref < (1u << 26) && p2.a[1].n_ref < (1u << 26);
+#define PCU_FLAT(FUSE) do { if (bal) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE, true>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); \
+                            else hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE, false>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); } while (0)
+        if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
+        else if (a.fuse == FUSE_ARGMAX) PCU_FLAT(FUSE_ARGMAX);
+        else PCU_FLAT(FUSE_NONE);
+#undef PCU_FLAT
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -567,9 +567,228 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     f_v = a.squared ? best : sqrt(best);
     f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
 }
+// -------------------------------------------------------------------------------------------------------
+// Balanced variant of the k = 1 main pass (float). Measured on MI355X (profiles/ubench/ta_rate.hip): a per-lane gather
+// instruction occupies the CU's texture-address path for ~17-21 cycles whatever its width (8/12/16 B) and HOWEVER FEW
+// LANES ARE ACTIVE (2 of 64: 21 cycles); k_search1_flat's 71 vector-memory instructions per wave x ~19 cycles are its
+// run time (TA busy 80 %), and its per-lane run loop executes max-over-lanes trips at ~30 % active lanes. Here the lanes
+// only scan their own centre row; the surviving cut runs of the other eight rows are cut into groups of 4 records and
+// pooled in a per-wave LDS queue, which the 64 lanes then consume TOGETHER, 64 groups per trip, whoever's they are:
+//   item   = (first record of the group) << 6 | owner lane                               [4 bytes]
+//   worker : owner's query from LDS, 4 records, minimum + which record, then
+//            old = ds_min_rtn_u64(key[owner], d2 bits << 32 | record offset)             [d2 >= 0: its bits order like the value]
+//            equal d2 from ANOTHER record (old, or twice inside the group) -> ds_min_u32(tie[owner], d2 bits)
+//   owner  : best = key >> 32, record = key & 0xffffffff, possible tie iff tie == best bits (flags are only raised at a
+//            value that was the running minimum, so the smallest flagged value equals the final minimum iff that minimum
+//            was met in two different records). A record seen twice (groups run past their run's end) has the same
+//            offset both times and raises nothing; no masking, no re-identification of the winner afterwards.
+// LDS is in order per wave, so the queue, the keys and the flags need no barrier beyond keeping the compiler from
+// reordering. Lanes beyond the end of the query list stay as workers. When a wave's groups exceed the queue the lanes past
+// the limit hand their queries to the wave-per-query pass (like lane_max_cand). Requires n_ref < 2^26.
+#ifndef PCU_BAL_QUEUE
+#define PCU_BAL_QUEUE 768
+#endif
+constexpr int kBalQueue = PCU_BAL_QUEUE;          // groups per wave (mean on uniform clouds: 260)
+template <bool EARLY, int FUSE>
+__device__ __forceinline__ void search1_bal_body(const SearchArgs<float>& a, const int nq_arg, const int bid, const int nblk, bool& f_ok, float& f_v, long long& f_key) {
+    typedef float T;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f32x4 s_q[kBlock];
+    __shared__ unsigned long long s_key[kBlock];
+    __shared__ unsigned s_tie[kBlock];
+    __shared__ unsigned s_item[kBlock / 64][kBalQueue];
+    const int per = nblk >> 3;
+    const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search
+    const int nq = a.qcount_dev ? *a.qcount_dev : nq_arg;
+    if (vb * kBlock >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wb = tid & ~63;
+    const bool alive = vb * kBlock + tid < nq;
+    const int t = alive ? vb * kBlock + tid : nq - 1;          // lanes past the end mirror the last query and only work for others
+    const int qpos = a.qlist ? a.qlist[t] : t;
+    const Pt4<T> q = a.qsorted[qpos];
+    const GridParams<T>& g = *a.gp;
+    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
+    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
+    const int len = x1 - x0 + 1;
+    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const unsigned cand_cap = a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u;
+    T best = Limits<T>::max_v;
+    unsigned brec = 0xffffffffu;
+    bool tie = false;
+    auto row_table = [&](int j, bool& ok, bool& odd) {
+        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
+        ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
+        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
+        odd = row & 1;
+        return *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
+    };
+    bool okj[9], oddj[9];
+    CellStart4 tb[9];
+    tb[0] = row_table(0, okj[0], oddj[0]);
+    if (EARLY) {
+#pragma unroll
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+    }
+    // ---- centre row: whole run, by its own lane (gives the minimum the other rows are cut against)
+    const unsigned cnt0 = (len == 3 ? tb[0].v[3] : (len == 2 ? tb[0].v[2] : tb[0].v[1])) - tb[0].v[0];
+    bool defer = cnt0 > cand_cap;
+    // Three groups per trip, all requested together (the kernel is a chain of memory round trips: one for 98 % of the waves
+    // instead of one per group; a wave ran 3.1 single-group trips on uniform clouds, so this issues no more loads). A lane
+    // whose run has ended fetches the +inf sentinel records, which change nothing.
+    {
+        const unsigned o0 = tb[0].v[0] * kRec;
+        const unsigned o1 = defer ? o0 : o0 + cnt0 * kRec;
+        const unsigned sent = a.n_ref * kRec;
+        auto eval = [&](const Pt4<T>& c0, const Pt4<T>& c1, const Pt4<T>& c2, const Pt4<T>& c3, const unsigned off) {
+            const T d0 = dist2_k1(q, c0), d1 = dist2_k1(q, c1), d2 = dist2_k1(q, c2), d3 = dist2_k1(q, c3);
+            const T m = min4(d0, d1, d2, d3);
+            const bool e0 = d0 == m, e1 = d1 == m, e2 = d2 == m, e3 = d3 == m;
+            const bool multi = (int)e0 + (int)e1 + (int)e2 + (int)e3 > 1;
+            const unsigned mrec = off + (e0 ? 0u : (e1 ? kRec : (e2 ? 2u * kRec : 3u * kRec)));
+            const bool lt = m < best, eq = m == best;
+            tie = lt ? multi : (tie || (eq && (multi || mrec != brec)));
+            brec = lt ? mrec : brec;
+            best = lt ? m : best;
+        };
+        for (unsigned off = o0; __any(off < o1); off += 12u * kRec) {
+            const unsigned f0 = off < o1 ? off : sent, f1 = off + 4u * kRec < o1 ? off + 4u * kRec : sent, f2 = off + 8u * kRec < o1 ? off + 8u * kRec : sent;
+            // (the loads are straight-line code: loads issued under a branch, even a wave-uniform one, are waited for at its end)
+            const Pt4<T>* p0 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f0);
+            const Pt4<T>* p1 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f1);
+            const Pt4<T>* p2 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f2);
+            const Pt4<T> c0 = p0[0], c1 = p0[1], c2 = p0[2], c3 = p0[3], c4 = p1[0], c5 = p1[1], c6 = p1[2], c7 = p1[3], c8 = p2[0], c9 = p2[1], c10 = p2[2], c11 = p2[3];
+            eval(c0, c1, c2, c3, f0);
+            eval(c4, c5, c6, c7, f1);
+            eval(c8, c9, c10, c11, f2);
+        }
+    }
+    if (!EARLY) {
+#pragma unroll
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+    }
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
+    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
+    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
+    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;
+    T my2[3], mz2[3];
+    {
+        T m;
+        my2[0] = (T)0; mz2[0] = (T)0;
+        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
+        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
+        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
+        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
+    }
+    unsigned total = cnt0;
+#pragma unroll
+    for (int j = 1; j < 9; ++j) total += okj[j] ? (len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1])) - tb[j].v[0] : 0u;
+    defer = defer || total > cand_cap;
+    // ---- the other rows: cut runs that survive the centre row's minimum, as groups of 4 records
+    unsigned rrec[8], rgrp[8];          // first record / number of groups of row j+1's cut run
+    unsigned ng = 0;
+#pragma unroll
+    for (int j = 1; j < 9; ++j) {
+        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
+        const T rlb = ry + rz;
+        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
+        const bool cut_first = oddj[j] ? cut_hi : cut_lo, cut_last = oddj[j] ? cut_lo : cut_hi;
+        const unsigned s_run = cut_first ? tb[j].v[1] : tb[j].v[0];
+        const unsigned e_full = len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1]);
+        const unsigned e_cut = len == 3 ? tb[j].v[2] : (len == 2 ? tb[j].v[1] : tb[j].v[0]);
+        const unsigned e_run = cut_last ? e_cut : e_full;
+        const bool on = alive && okj[j] && !defer && !(best < rlb) && e_run > s_run;
+        rrec[j - 1] = s_run;
+        rgrp[j - 1] = on ? (e_run - s_run + 3u) >> 2 : 0u;
+        ng += rgrp[j - 1];
+    }
+    // the lane's slice of the wave's queue; lanes whose slice would end beyond the queue (a prefix property: all lanes from the
+    // first such one on) hand their queries to the wave-per-query pass
+    unsigned inc = ng;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    const bool fits = inc <= (unsigned)kBalQueue;
+    const unsigned long long fit_mask = __ballot(fits);
+    if (!fits) {
+        defer = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rgrp[j] = 0;
+    }
+    const int n_items = fit_mask ? (int)__shfl(inc, 63 - __clzll((long long)fit_mask), 64) : 0;
+    s_q[tid] = f32x4{q.x, q.y, q.z, 0.f};
+    s_key[tid] = ((unsigned long long)__float_as_uint(best) << 32) | brec;
+    s_tie[tid] = tie ? __float_as_uint(best) : 0xffffffffu;
+    unsigned* const items = s_item[wv];
+    {
+        unsigned pos = inc - ng;          // (deferred lanes write nothing)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            for (unsigned gi = 0; __any(gi < rgrp[j]); ++gi)
+                if (gi < rgrp[j]) items[pos + gi] = ((rrec[j] + 4u * gi) << 6) | (unsigned)lane;
+            pos += rgrp[j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- the queue, 64 groups per trip; the next trip's item and records are requested before this trip's are evaluated
+    if (n_items > 0) {
+        const int last = n_items - 1;
+#define PCU_BAL_EVAL(IT, C0, C1, C2, C3)                                                                              \
+        {                                                                                                             \
+            const unsigned own_ = (unsigned)wb + ((IT) & 63u), off_ = ((IT) & 0xffffffc0u) >> 2;                      \
+            const f32x4 oq_ = s_q[own_];                                                                              \
+            Pt4<T> Q_; Q_.x = oq_.x; Q_.y = oq_.y; Q_.z = oq_.z;                                                      \
+            const T d0_ = dist2_k1(Q_, C0), d1_ = dist2_k1(Q_, C1), d2_ = dist2_k1(Q_, C2), d3_ = dist2_k1(Q_, C3);   \
+            const T m_ = min4(d0_, d1_, d2_, d3_);                                                                    \
+            const bool e0_ = d0_ == m_, e1_ = d1_ == m_, e2_ = d2_ == m_, e3_ = d3_ == m_;                            \
+            const bool multi_ = (int)e0_ + (int)e1_ + (int)e2_ + (int)e3_ > 1;                                        \
+            const unsigned mrec_ = off_ + (e0_ ? 0u : (e1_ ? kRec : (e2_ ? 2u * kRec : 3u * kRec)));                  \
+            const unsigned mb_ = __float_as_uint(m_);                                                                 \
+            const unsigned long long old_ = atomicMin(&s_key[own_], ((unsigned long long)mb_ << 32) | mrec_);         \
+            if (multi_ || ((unsigned)(old_ >> 32) == mb_ && (unsigned)old_ != mrec_)) atomicMin(&s_tie[own_], mb_);   \
+        }
+        for (int i0 = 0; i0 < n_items; i0 += 128) {           // two trips' items and records requested together, branch-free
+            const unsigned ia = items[min(i0 + lane, last)], ib = items[min(i0 + 64 + lane, last)];        // (past the end: the last item again -- no effect)
+            const Pt4<T>* pa = reinterpret_cast<const Pt4<T>*>(base + (size_t)((ia & 0xffffffc0u) >> 2));
+            const Pt4<T>* pb = reinterpret_cast<const Pt4<T>*>(base + (size_t)((ib & 0xffffffc0u) >> 2));
+            const Pt4<T> a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+            PCU_BAL_EVAL(ia, a0, a1, a2, a3)
+            PCU_BAL_EVAL(ib, b0, b1, b2, b3)
+        }
+#undef PCU_BAL_EVAL
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!alive) return;
+    {
+        const unsigned long long key = s_key[tid];
+        best = __uint_as_float((unsigned)(key >> 32));
+        brec = (unsigned)key;
+        tie = s_tie[tid] == (unsigned)(key >> 32);
+    }
+    T bd[1] = {best};
+    int bi[1] = {0x7fffffff};
+    if (FUSE != FUSE_SUM && brec != 0xffffffffu) bi[0] = reinterpret_cast<const Pt4<T>*>(base + (size_t)brec)->idx;      // (a sum needs no index: one round trip less)
+    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
+    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
+    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer); return; }
+    if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
+        wave_append(true, qpos, a.ties, a.n_ties);
+        return;
+    }
+    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const bool certified = best < lb;
+    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
+    f_ok = certified;
+    f_v = a.squared ? best : sqrt(best);
+    f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
+}
+
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
 template <typename T> struct SearchArgs2 { SearchArgs<T> a[2]; };
-template <typename T, bool EARLY, int MINW, int FUSE>
+template <typename T, bool EARLY, int MINW, int FUSE, bool BAL = false>
 __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2<T> p, int nb0) {
     // (the side's arguments are read through an index into the kernel-argument segment; selecting between two by-value
     // structs by reference makes the compiler copy the chosen one to scratch)
@@ -579,7 +798,8 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
     // (nq is picked by a scalar select: read through p.a[side] the compiler parks both sides' values in SCRATCH to index them --
     // 8 bytes of private memory written per lane, 16 MB of HBM writes per 1M-vs-1M launch, profiles/r02a_pmc.txt)
     const int nq_side = side ? p.a[1].nq : p.a[0].nq;
-    search1_flat_body<T, EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
+    if constexpr (BAL && sizeof(T) == 4) search1_bal_body<EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
+    else search1_flat_body<T, EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
     if (FUSE == FUSE_SUM) {                     // one fp64 partial per block; lanes in a fixed order: reproducible
         const double r = block_sum(ok ? (double)v : 0.0);
         if (threadIdx.x == 0) p.a[side].f_sum[bid] = r;

@@ -149,3 +149,33 @@ def test_squeeze_of_singleton_shapes(pcu):
     assert d.shape == () and c.shape == () and c.dtype == np.int64
     d, c = pcu.k_nearest_neighbors(q, r, 3)
     assert d.shape == (3,) and c.shape == (3,)
+
+
+@pytest.mark.gpu
+def test_opt_in_balanced_lane_pass_is_identical(pcu, tmp_path):
+    """PCU_HIP_BAL=1 selects the work-queue variant of the k = 1 lane pass (search.h: search1_bal_body). It is opt-in because it
+    is not faster, but it must return the same bits: indices, distances, Chamfer and Hausdorff values of a run with the variable
+    set (a child process: the switch is read once) are compared with this process's results."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(77)
+    x = rng.random((200_000, 3), dtype=np.float32)
+    y = rng.random((150_000, 3), dtype=np.float32)
+    y[:500] = x[:500]                                   # exact zeros and exact ties (duplicated rows)
+    y[500:1000] = y[1000:1500]
+    np.save(tmp_path / "x.npy", x); np.save(tmp_path / "y.npy", y)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
+        "x = np.load(%r); y = np.load(%r)\n"
+        "d, i = pcu.k_nearest_neighbors(x, y, 1)\n"
+        "h = pcu.hausdorff_distance(x, y, return_index=True)\n"
+        "c = pcu.chamfer_distance(x, y)\n"
+        "np.savez(%r, d=d, i=i, h=np.array(h, dtype=np.float64), c=np.float64(c))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "x.npy"), str(tmp_path / "y.npy"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, PCU_HIP_BAL="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+    got = np.load(tmp_path / "out.npz")
+    d, i = pcu.k_nearest_neighbors(x, y, 1)
+    assert np.array_equal(got["i"], i) and np.array_equal(got["d"].view(np.uint32), np.asarray(d).view(np.uint32))
+    assert np.array_equal(got["h"], np.array(pcu.hausdorff_distance(x, y, return_index=True), dtype=np.float64))
+    assert float(got["c"]) == float(pcu.chamfer_distance(x, y))
