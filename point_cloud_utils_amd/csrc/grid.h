@@ -475,6 +475,7 @@ struct BucketSide {        // one cloud's view of the bucket passes
     const T* pts; int n; GridParams<T>* gp; int shift; int nb_stride;
     unsigned *bucket_total, *block_base, *bucket_start; Pt4<T>* tmp; unsigned *cell_start, *rank_tmp;
     Pt4<T>* sorted; unsigned *pos_of, *large_list, *n_large;
+    unsigned cap;          // > 0: one-pass build -- bucket b owns the slot tmp[b * cap, (b + 1) * cap), bucket_total[b] = its fill (k_bucket_onepass)
 };
 template <typename T>
 __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const BucketSide<T> a0, const BucketSide<T> a1, int nb0) {
@@ -483,6 +484,59 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const BucketSide<T>
     bucket_count_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.block_base, a.nb_stride);
 }
 
+
+// One-pass variant of count + scatter (the default for whole-call builds): every bucket owns a fixed slot of `cap` records in
+// `tmp` (cap = kLargeBucket = twice the expected fill), so a block can reserve its share of a bucket with the one returning
+// atomic per (block, non-empty bucket) that k_bucket_count spends anyway and write its records at once -- the points are read
+// once instead of twice and one launch goes away. No bucket start is known yet: k_bucket_sort derives its output offset from
+// the fills. A bucket that would overflow its slot (clusters, surfaces: the data the two-pass build has k_bucket_large for)
+// raises GridParams::has_large = 2: the index is then incomplete, every search pass gives up at once, and the host rebuilds
+// with the two-pass pipeline and keeps to it for this context (pcu_hip.hip: search_finish).
+template <typename T>
+__device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __restrict__ pts, int n, GridParams<T>* gp, int shift, unsigned* fill,
+                                                   Pt4<T>* __restrict__ tmp, const unsigned cap) {
+    __shared__ unsigned s_cnt[kBkMaxBuckets];      // the block's count per bucket, then the slot position of its first record
+    const GridParams<T>& g = *gp;
+    const int NB = (g.ncells + (1 << shift) - 1) >> shift;
+    for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
+    __syncthreads();
+    const int base = bid * kBkBlockPts;
+    T px[kBkPts], py[kBkPts], pz[kBkPts];
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const int i = min(base + j * kBkThreads + (int)threadIdx.x, n - 1);
+        px[j] = pts[3 * (size_t)i]; py[j] = pts[3 * (size_t)i + 1]; pz[j] = pts[3 * (size_t)i + 2];
+    }
+    unsigned bk[kBkPts], rk[kBkPts];
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const bool valid = base + j * kBkThreads + (int)threadIdx.x < n;
+        bk[j] = cell_linear(g, px[j], py[j], pz[j]) >> shift;
+        rk[j] = count_rank(s_cnt, bk[j], valid);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += kBkThreads) {
+        const unsigned c = s_cnt[i];
+        if (c) {
+            const unsigned at = atomicAdd(&fill[i], c);
+            if (at + c > cap) gp->has_large = 2;
+            s_cnt[i] = (unsigned)i * cap + at;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kBkPts; ++j) {
+        const int i = base + j * kBkThreads + (int)threadIdx.x;
+        const unsigned pos = s_cnt[bk[j]] + rk[j];
+        if (i < n && pos < (bk[j] + 1u) * cap) { Pt4<T> p; p.x = px[j]; p.y = py[j]; p.z = pz[j]; p.idx = i; tmp[pos] = p; }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass(const BucketSide<T> a0, const BucketSide<T> a1, int nb0) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const BucketSide<T>& a = second ? a1 : a0;
+    bucket_onepass_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.tmp, a.cap);
+}
 
 template <typename T>
 __device__ __forceinline__ void bucket_scatter_body(const int bid, const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, int shift,
@@ -554,7 +608,7 @@ template <typename T>
 __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
                                                               const Pt4<T>* __restrict__ tmp, unsigned* cell_start, Pt4<T>* __restrict__ sorted,
                                                               unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large,
-                                                              long long* prof, const int cnt_cap) {
+                                                              long long* prof, const int cnt_cap, const unsigned cap, const unsigned* __restrict__ fill) {
     // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
     long long t_prev = prof ? wall_clock64() : 0;
 #define BK_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
@@ -572,7 +626,20 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned c0 = (unsigned)b << shift;
     const int ncl = min(CB, g.ncells - (int)c0);
-    const unsigned s = bucket_start[b], e = bucket_start[b + 1];
+    // records of the bucket: tmp[s_in, s_in + (e - s)); its slice of `sorted`: [s, e)
+    unsigned s, e, s_in;
+    if (cap) {            // one-pass build: the bucket's slot; its output offset = the fills of the buckets before it
+        unsigned part = 0;
+        for (int i = tid; i < b; i += kSortThreads) part += min(fill[i], cap);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) s_w[wave] = part;
+        __syncthreads();
+        s = 0;
+        for (int w = 0; w < kSortThreads / 64; ++w) s += s_w[w];
+        __syncthreads();
+        e = s + min(fill[b], cap); s_in = (unsigned)b * cap;
+    } else { s = bucket_start[b]; e = bucket_start[b + 1]; s_in = s; }
     const bool large = e - s > kLargeBucket;
     BK_PROF(0);
     for (int i = tid; i < CB; i += kSortThreads) s_cnt[i] = (large && i < ncl) ? cell_start[c0 + i] : 0u;
@@ -582,6 +649,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
     // Records are fetched kSortBatch trips at a time, all loads of a batch in flight together (clamped index instead of a
     // branch around the load); the batch loop ends, wave-uniformly, with the bucket.
     constexpr int kSortBatch = 4;
+    const unsigned in_off = s_in - s;           // tmp index = sorted index + in_off (mod 2^32)
     const unsigned last = e > s ? e - 1u : s;
     const bool staged = e - s <= (unsigned)kStageRecs;      // the bucket fits the LDS stage (the normal case)
     if (!large) {
@@ -591,7 +659,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
             const bool batch_on = s + (unsigned)(it0 * kSortThreads) < e;       // uniform in the block
             if (batch_on) {
 #pragma unroll
-                for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
+                for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last) + in_off];
             }
 #pragma unroll
             for (int u = 0; u < kSortBatch; ++u) {
@@ -673,7 +741,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
             if (!(s + (unsigned)(it0 * kSortThreads) < e)) break;                  // uniform in the block
             Pt4<T> rec[kSortBatch];
 #pragma unroll
-            for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last)];
+            for (int u = 0; u < kSortBatch; ++u) rec[u] = tmp[min(s + (unsigned)((it0 + u) * kSortThreads + tid), last) + in_off];
 #pragma unroll
             for (int u = 0; u < kSortBatch; ++u) {
                 const unsigned p = s + (unsigned)((it0 + u) * kSortThreads + tid);
@@ -694,7 +762,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const BucketSide<T
     const bool second = (int)blockIdx.x >= nb0;
     const BucketSide<T>& a = second ? a1 : a0;
     bucket_sort_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.gp, a.shift, a.bucket_start, a.tmp, a.cell_start, a.sorted, a.pos_of,
-                        a.large_list, a.n_large, prof, cnt_cap);
+                        a.large_list, a.n_large, prof, cnt_cap, a.cap, a.bucket_total);
 }
 template <typename T>
 static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + (size_t)kStageRecs * sizeof(Pt4<T>); }

@@ -70,6 +70,7 @@ struct pcu_hip_ctx {
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
     unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
+    bool two_pass = false;                    // sticky: a one-pass index build of this context overflowed a bucket slot (grid.h: k_bucket_onepass)
     bool eager_large = false;                 // sticky: this context has met clouds with over-full buckets (surfaces, clusters): launch their
                                               // placement (k_bucket_large) with every build instead of on demand
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
@@ -183,6 +184,8 @@ struct GridIndex {
     bool bucketed = false; int shift = 0, nb_max = 0, n_zero = 0;
     double h_want = 0.0;                  // > 0: cells at least this large (fixed-radius searches)
     Pt4<T>* tmp = nullptr; unsigned *bucket_total = nullptr, *bucket_start = nullptr, *block_base = nullptr, *large_list = nullptr, *n_large = nullptr;
+    bool one_pass = false;                // build with k_bucket_onepass (tmp holds nb_max slots of kLargeBucket records); cleared after an overflow
+    const T* src = nullptr; double occ_built = 0.0;       // what the index was built from (rebuild after an overflow)
 };
 
 static int max_cells_for(int64_t n, double occ) {
@@ -214,12 +217,12 @@ static size_t index_bytes(int64_t n, double occ) {
                2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
     int sh = 0, nb = 0;
     if (bucket_plan(n, occ, &sh, &nb))
-        b += align_up((size_t)n * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
+        b += align_up(std::max((size_t)n, (size_t)nb * kLargeBucket) * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
              align_up((size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * nb * 4, 256);
     return b;
 }
 template <typename T>
-static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool want_pos = false, bool allow_bucketed = true) {
+static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool want_pos = false, bool allow_bucketed = true, bool one_pass = false) {
     g.n = (int)n; g.max_cells = max_cells_for(n, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
     g.bucketed = allow_bucketed && bucket_plan(n, occ, &g.shift, &g.nb_max);
     if (aalloc(a, &g.gp, 1)) return -1;
@@ -232,7 +235,8 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
     g.n_zero = g.max_cells + 1;
     if (g.bucketed) {
         g.bucket_total = g.cell_start + g.max_cells + 1; g.n_large = g.bucket_total + g.nb_max; g.n_zero = g.max_cells + 1 + g.nb_max + 1;
-        if (aalloc(a, &g.tmp, (size_t)n)) return -1;
+        g.one_pass = one_pass;
+        if (aalloc(a, &g.tmp, one_pass ? std::max((size_t)n, (size_t)g.nb_max * kLargeBucket) : (size_t)n)) return -1;
         if (aalloc(a, &g.bucket_start, (size_t)g.nb_max + 1) || aalloc(a, &g.large_list, (size_t)g.nb_max + 1)) return -1;
         if (aalloc(a, &g.block_base, (size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * g.nb_max)) return -1;
         g.pos_of = want_pos ? g.cell_of : nullptr;      // cell_of is not used by this build
@@ -260,11 +264,15 @@ static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipSt
 template <typename T>
 static BucketSide<T> bucket_side(const GridIndex<T>& g, const T* pts) {
     return BucketSide<T>{pts, g.n, g.gp, g.shift, g.nb_max, g.bucket_total, g.block_base, g.bucket_start, g.tmp, g.cell_start, g.rank,
-                         g.sorted, g.pos_of, g.large_list, g.n_large};
+                         g.sorted, g.pos_of, g.large_list, g.n_large, g.one_pass ? kLargeBucket : 0u};
 }
 template <typename T>
 static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex<T>* b, const T* pb, double occb, hipStream_t s,
                             bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, unsigned* tickets = nullptr) {
+    a.src = pa; a.occ_built = occa;
+    if (b) { b->src = pb; b->occ_built = occb; }
+    // one launch set serves both clouds only if they are built the same way
+    if (b && a.bucketed && b->bucketed && a.one_pass != b->one_pass) a.one_pass = b->one_pass = false;
     {
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
@@ -288,8 +296,12 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     if (nbs) {
         const BucketSide<T> s0 = bucket_side(*bs[0], bp[0]), s1 = nbs > 1 ? bucket_side(*bs[1], bp[1]) : s0;
         const int c0 = (bs[0]->n + kBkBlockPts - 1) / kBkBlockPts, c1 = nbs > 1 ? (bs[1]->n + kBkBlockPts - 1) / kBkBlockPts : 0;
-        hipLaunchKernelGGL(k_bucket_count<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
-        hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+        const bool one_pass = bs[0]->one_pass;
+        if (one_pass) hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+        else {
+            hipLaunchKernelGGL(k_bucket_count<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+            hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+        }
         static long long* prof = nullptr;       // PCU_HIP_PROF_BUILD: stage times of k_bucket_sort, printed per build (synchronises)
         static const bool do_prof = getenv("PCU_HIP_PROF_BUILD") != nullptr;
         if (do_prof && !prof) HIP_TRY(hipMalloc((void**)&prof, 8 * sizeof(long long)));
@@ -318,7 +330,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             fprintf(stderr, "[bucket_sort prof] blocks %lld | mean us per block: head %.2f  zero+sync %.2f  load+rank %.2f  scan %.2f  place %.2f\n", h[7],
                     h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0, h[4] / nb / 100.0);
         }
-        if (!defer_large) index_large_pass<T>(a, b, s);
+        if (!defer_large && !one_pass) index_large_pass<T>(a, b, s);        // (a one-pass build has no over-full buckets: it overflows instead)
     }
     for (int side = 0; side < (b ? 2 : 1); ++side) {
         GridIndex<T>& g = side ? *b : a;
@@ -403,6 +415,8 @@ constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced wh
 #endif
 constexpr int kWaveBlocks = PCU_WAVE_BLOCKS;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
+// whole-call index builds use the one-pass bucket scatter until a cloud of this context overflows a slot (PCU_HIP_TWO_PASS=1: never)
+static bool use_one_pass(const pcu_hip_ctx* c) { static const bool off = getenv("PCU_HIP_TWO_PASS") != nullptr; return !off && !c->two_pass; }
 static bool use_gather_kernels() { static const bool v = getenv("PCU_HIP_TILE") == nullptr; return v; }
 static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }
 static int grid8(int nwork, int tb) { return (((nwork + tb - 1) / tb) + 7) / 8 * 8; }       // multiple of 8: XCD-aware block map
@@ -776,8 +790,17 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     int hc_redo[C_N], hc_large[C_N];
     bool redone = false;
     if (hc[C_LARGE]) {
-        // Over-full buckets of a bucketed index were still unplaced (their placement, k_bucket_large, is only launched on demand):
-        // every pass gave up at once. Place them -- for the query cloud and the dataset -- and run the passes again.
+        // Every pass gave up at once because an index was not ready (GridParams::has_large).
+        if (hc[C_LARGE] & 2) {
+            // A one-pass build overflowed a bucket slot (uneven data): rebuild with the two-pass pipeline, which has k_bucket_large
+            // for such buckets, and keep to it in this context.
+            c->two_pass = true; c->eager_large = true;
+            GridIndex<T>* ov[2] = {&j.qidx, &j.ridx};
+            for (GridIndex<T>* g : ov)
+                if (g->one_pass) { g->one_pass = false; if (index_build<T>(*g, g->src, g->occ_built, s)) return -1; if (st) st->n_grid_builds += 1; }
+        }
+        // Over-full buckets of a bucketed index were still unplaced (their placement, k_bucket_large, is only launched on demand).
+        // Place them -- for the query cloud and the dataset -- and run the passes again.
         index_large_pass<T>(j.qidx, &j.ridx, s);
         c->eager_large = true;                   // data of this kind will come again (mesh samples: +0.18 ms per call for the round trip)
         if (search_enqueue(c, s, j, st)) return -1;
@@ -1038,8 +1061,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         const bool row_out = k >= 4;
         job.row_out = row_out;
         if (pidx) job.ridx = index_grid<T>(pidx);
-        else if ((rc = index_alloc(ar, job.ridx, nr, occ))) break;
-        if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/!row_out))) break;
+        else if ((rc = index_alloc(ar, job.ridx, nr, occ, false, true, use_one_pass(c)))) break;
+        if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/!row_out, true, use_one_pass(c)))) break;
         ResultBlock* rb = nullptr;
         if ((rc = aalloc(ar, &rb, 1))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
@@ -1142,7 +1165,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
-    if (index_alloc(ar, ix, nx, occ, want_pos_x) || index_alloc(ar, iy, ny, occ, want_pos_y)) return -1;
+    if (index_alloc(ar, ix, nx, occ, want_pos_x, true, use_one_pass(c)) || index_alloc(ar, iy, ny, occ, want_pos_y, true, use_one_pass(c))) return -1;
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;

@@ -48,9 +48,10 @@ struct SearchArgs {
                                     // must not turn a wave into a millisecond-long pole
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then refits the dataset grid (pcu_hip.hip, search_finish)
-    const GridParams<T>* qgp;       // grid of the QUERY cloud: a pass gives up (flag word skew_flag[kLargeFlag]) when either cloud's bucketed
-                                    // index still has unplaced over-full buckets (GridParams::has_large); the host then runs
-                                    // k_bucket_large and repeats the pass -- the common case saves that launch
+    const GridParams<T>* qgp;       // grid of the QUERY cloud: a pass gives up (flag word skew_flag[kLargeFlag] = the OR of both clouds'
+                                    // GridParams::has_large) when either cloud's bucketed index is not ready: 1 = over-full buckets still
+                                    // unplaced (the host runs k_bucket_large and repeats the pass -- the common case saves that launch),
+                                    // 2 = a one-pass build overflowed a bucket slot (the host rebuilds with the two-pass pipeline)
     int kreq;                       // neighbours requested (<= K)
     int squared;                    // write d2 instead of sqrt(d2)
     int row_out;                    // 1: result row of a query goes to its ORIGINAL row (k >= 4: rows are >= 48 B, scattering whole
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
-    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
+    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
 
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
@@ -403,7 +404,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
-    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
+    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -608,7 +609,7 @@ __device__ __forceinline__ void search1_bal_body(const SearchArgs<float>& a, con
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
-    if (g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = 1; return; }
+    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
     if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
-    if (g.has_large | a.qgp->has_large) { if (t0 == 0 && lane == 0) a.skew_flag[kLargeFlag] = 1; return; }
+    if (const int hl = g.has_large | a.qgp->has_large) { if (t0 == 0 && lane == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -971,8 +972,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
     if (a0.skew_limit > 0.f && (float)ss0 > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
     if (njobs > 1 && a1.skew_limit > 0.f && (float)ss1 > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
-    if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = 1; total0 = 0; }
-    if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = 1; total1 = 0; }
+    if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = hl0; total0 = 0; }
+    if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = hl1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
         const bool job1 = wg >= total0;
         const SearchArgs<T>& a = job1 ? a1 : a0;
