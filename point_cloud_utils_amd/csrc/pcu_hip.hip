@@ -1063,6 +1063,8 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (pidx) job.ridx = index_grid<T>(pidx);
         else if ((rc = index_alloc(ar, job.ridx, nr, occ, false, true, use_one_pass(c)))) break;
         if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/!row_out, true, use_one_pass(c)))) break;
+        job.qidx.src = dq; job.qidx.occ_built = occ_q;
+        if (!pidx) { job.ridx.src = dr; job.ridx.occ_built = occ; }
         ResultBlock* rb = nullptr;
         if ((rc = aalloc(ar, &rb, 1))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
@@ -1166,6 +1168,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
     if (index_alloc(ar, ix, nx, occ, want_pos_x, true, use_one_pass(c)) || index_alloc(ar, iy, ny, occ, want_pos_y, true, use_one_pass(c))) return -1;
+    ix.src = P.dx; iy.src = P.dy; ix.occ_built = iy.occ_built = occ;        // (the jobs below hold copies: what a rebuild after a slot overflow starts from)
+    if (ix.bucketed && iy.bucketed && ix.one_pass != iy.one_pass) ix.one_pass = iy.one_pass = false;
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;

@@ -179,3 +179,36 @@ def test_opt_in_balanced_lane_pass_is_identical(pcu, tmp_path):
     assert np.array_equal(got["i"], i) and np.array_equal(got["d"].view(np.uint32), np.asarray(d).view(np.uint32))
     assert np.array_equal(got["h"], np.array(pcu.hausdorff_distance(x, y, return_index=True), dtype=np.float64))
     assert float(got["c"]) == float(pcu.chamfer_distance(x, y))
+
+
+@pytest.mark.gpu
+def test_one_pass_build_overflow_falls_back(pcu, oracle_kind):
+    """Uneven clouds overflow the fixed bucket slots of the one-pass index build (grid.h: k_bucket_onepass): every search pass
+    gives up, the host rebuilds with the two-pass pipeline (pcu_hip.hip: search_finish) and the results are the reference's.
+    Fresh contexts (a new device context per thread) so that the first call of each op takes the overflow path."""
+    import threading
+    rng = np.random.default_rng(31)
+    x = rng.normal(0.5, 0.05, (300_000, 3)).astype(np.float32)
+    y = rng.normal(0.5, 0.05, (250_000, 3)).astype(np.float32)
+    d0, i0 = oracle.k_nearest_neighbors(x, y, 1, kind=oracle_kind)
+    c0 = oracle.chamfer_distance(x, y, kind=oracle_kind)
+    h0 = oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind)
+    res = {}
+
+    def run(name, fn):
+        def body():
+            try:
+                res[name] = fn()
+            except Exception as e:      # surfaced below
+                res[name] = e
+        t = threading.Thread(target=body); t.start(); t.join()
+    run("knn", lambda: pcu.k_nearest_neighbors(x, y, 1))
+    run("chamfer", lambda: (pcu.chamfer_distance(x, y), pcu.chamfer_distance(x, y)))
+    run("hausdorff", lambda: pcu.hausdorff_distance(x, y, return_index=True))
+    for v in res.values():
+        if isinstance(v, Exception):
+            raise v
+    d, i = res["knn"]
+    assert np.array_equal(i, i0) and np.array_equal(np.asarray(d).view(np.uint32), np.asarray(d0).view(np.uint32))
+    assert abs(float(res["chamfer"][0]) - float(c0)) <= 1e-4 * float(c0) and float(res["chamfer"][0]) == float(res["chamfer"][1])
+    assert tuple(res["hausdorff"]) == tuple(h0)
