@@ -70,6 +70,8 @@ struct pcu_hip_ctx {
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
     unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
+    double occ_scale[2] = {1.0, 1.0};         // sticky: grid resolution of the first / second cloud of a call relative to the default (rescale_wanted:
+                                              // surface-like clouds want finer cells); a k_nearest_neighbors dataset counts as the second cloud
     bool two_pass = false;                    // sticky: a one-pass index build of this context overflowed a bucket slot (grid.h: k_bucket_onepass)
     bool eager_large = false;                 // sticky: this context has met clouds with over-full buckets (surfaces, clusters): launch their
                                               // placement (k_bucket_large) with every build instead of on demand
@@ -410,6 +412,19 @@ constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 12
 constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
 constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
                                         // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)
+// Occupancy rescale. The default occupancy is right for clouds that fill their bounding box. A cloud sampled from a surface puts
+// its points into a thin shell of cells: at 1M points the occupied cells hold ~50 points instead of 2 and the lane pass scans
+// 9 x 50 candidates (sphere surface 0.39 ms, mesh samples 0.49 ms per Chamfer against 0.17 ms uniform). The balance metric the
+// bucket sort already computes (sumsq / n = mean number of cell mates) shows it: above kRescaleAbove x (occupancy + 1) the passes
+// give up at once, the host restarts the call with cells finer by sqrt(ratio) in volume (measured optimum on surfaces: 4-8x
+// finer, 0.27-0.28 ms) and the context keeps that scale for its next calls; a call that then meets a cloud that is as even as
+// a volume-filling one at the finer scale (ratio below kRescaleBelow -- such a cloud would be 20x slower on too fine a grid)
+// restarts with the default. Ratios above kSkewFactor still take the refit path. Off when the caller fixes the occupancy
+// (pcu_hip_ctx_set_cell_occupancy), for persistent indexes, and with PCU_HIP_NO_RESCALE.
+constexpr double kRescaleAbove = 6.0, kRescaleBelow = 3.0, kRescaleMax = 8.0;
+constexpr int PCU_RETRY = 1000;         // internal: restart the call (the context's occ_scale changed)
+static bool rescale_enabled(const pcu_hip_ctx* c) { static const bool off = getenv("PCU_HIP_NO_RESCALE") != nullptr; return !off && !(c->occupancy > 0); }
+static double call_occupancy(const pcu_hip_ctx* c, int k, int role) { return c->occupancy > 0 ? c->occupancy : default_occupancy(k) * c->occ_scale[role]; }
 #ifndef PCU_WAVE_BLOCKS
 #define PCU_WAVE_BLOCKS 512
 #endif
@@ -508,6 +523,8 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     int leaf_max = 10; bool tie_order = true;   // reference's max_points_per_leaf: defines the order of exact ties
     int n_tt = 0;                               // genuine-tie queries found (filled by search_finish)
     bool skew_check = true;                     // give up early on a badly unbalanced dataset grid (then: refitted finer grids)
+    double skew_hi = kSkewFactor, skew_lo = 0.0; // ... thresholds on sumsq / n / (occ + 1); rescale: see kRescaleAbove
+    bool may_rescale = false; int role = 1;      // role: which cloud of the call the dataset is (pcu_hip_ctx::occ_scale)
     GridIndex<T> fine[2]; int n_fine = 0;       // finer dataset grids for the dense parts, finest first (unbalanced clouds only)
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
@@ -525,7 +542,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0; a.row_out = j.row_out ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
-    a.skew_limit = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
+    a.skew_limit = 0.f; a.skew_lo = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.qgp = j.qidx.gp;
     a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
@@ -558,7 +575,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.n_unresolved = sc.counters + (last ? C_U1 : (lv == 0 ? C_X0 : C_X1));
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
             // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
-            if (last && j.skew_check && j.n_fine == 0) a.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
+            if (last && j.skew_check && j.n_fine == 0) { a.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
             const bool time_it = st && c->time_kernels && lv == 0 && c->n_kev + 2 <= 8;
             if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
             if (launch_search_fast<T>(KF, a, j.qidx.n, s, /*open_index=*/last)) return -1;
@@ -574,9 +591,9 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         if (j.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
-        if (j.skew_check) b.skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
+        if (j.skew_check) { b.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); b.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
         if (launch_search_wave<T>(KL, b, s)) return -1;
-        b.nq = 0; b.skew_limit = 0.f;
+        b.nq = 0; b.skew_limit = 0.f; b.skew_lo = 0.f;
         b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;             // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
         if (launch_search_wave<T>(KL, b, s)) return -1;
@@ -605,7 +622,7 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
         a[d].nq = j.qidx.n; a[d].R = 1;
         a[d].unresolved = sc.u1; a[d].n_unresolved = sc.counters + C_U1;
         a[d].ties = sc.t1; a[d].n_ties = sc.counters + C_T1;
-        if (j.skew_check) a[d].skew_limit = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n);
+        if (j.skew_check) { a[d].skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a[d].skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
         b[d] = base_args(j, j.ridx);
         b[d].ties = sc.tt; b[d].n_ties = sc.counters + C_TT;
         b[d].qlist = sc.t1; b[d].qcount_dev = sc.counters + C_T1; b[d].R = 1;            // possible ties -> total order, radius 1
@@ -780,9 +797,37 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     return 0;
 }
 
+// Thresholds of a whole-call job (not for persistent indexes): see kRescaleAbove.
+template <typename T>
+static void job_rescale_setup(const pcu_hip_ctx* c, SearchJob<T>& j, bool allowed, int role) {
+    j.may_rescale = allowed && rescale_enabled(c); j.role = role;
+    if (!j.may_rescale) return;
+    if (c->occ_scale[role] >= 1.0) j.skew_hi = kRescaleAbove; else j.skew_lo = kRescaleBelow;
+}
+// A pass gave up on the balance check: is it a case for a different grid resolution (then c->occ_scale is updated and the caller
+// restarts the call) or for the refit machinery (false)?
+template <typename T>
+static bool rescale_wanted(pcu_hip_ctx* c, const SearchJob<T>& j, hipStream_t s) {
+    if (!j.may_rescale) return false;
+    GridParams<T> hg;
+    if (hipMemcpyAsync(&hg, j.ridx.gp, sizeof hg, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+    const double r = (double)hg.sumsq / (double)j.ridx.n / (j.occ + 1.0);
+    double& scale = c->occ_scale[j.role];
+    if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[rescale] cloud %d n=%d occ=%.3f scale=%.3f ratio=%.2f\n", j.role, j.ridx.n, j.occ, scale, r);
+    if (scale >= 1.0) {
+        if (r > kRescaleAbove && r <= kSkewFactor) { scale = 1.0 / std::min(kRescaleMax, sqrt(r)); return true; }
+        return false;
+    }
+    // a finer grid kept from earlier calls: back to the default when this cloud is even at that scale, or so uneven that it is a
+    // case for the refit path (which works from the default resolution)
+    if (r < kRescaleBelow || r > kSkewFactor) { scale = 1.0; return true; }
+    return false;
+}
+
 // After the call's single read-back + stream sync: look at the counters; finish whatever is still unresolved with coarser dataset grids
 // (host-driven, one sync per pass; only far-away / isolated queries ever get here).
-// Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, <0 on error.
+// Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, 3 if the call is to be restarted (rescale_wanted),
+// <0 on error.
 template <typename T>
 static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc) {
     // hc: host copy of j.sc.counters, read back by the caller together with the call's scalar results
@@ -808,6 +853,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         HIP_TRY(hipStreamSynchronize(s));
         hc = hc_large; redone = true;
     }
+    if (hc[C_SKEW] && rescale_wanted(c, j, s)) return 3;          // 3: restart the call at another grid resolution
     if (hc[C_SKEW]) {
         // The dataset grid is badly unbalanced (clusters, blobs, a far outlier inflating the bbox): every pass gave up
         // at once. Refit: same cell count over the core range of the cloud (replaces `ridx`), then up to two finer
@@ -1023,8 +1069,8 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
 }
 
 template <typename T>
-static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
-                    T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx = nullptr) {
+static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
+                       T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx, int restarts) {
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (pidx) {
         if (pidx->elem_size != (int)sizeof(T)) return fail(PCU_HIP_ERR_INVALID, "the index was built for the other floating-point type");
@@ -1038,7 +1084,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
-    const double occ = pidx ? pidx->occ : (c->occupancy > 0 ? c->occupancy : default_occupancy(k));
+    const double occ = pidx ? pidx->occ : call_occupancy(c, k, 1);
     const double occ_q = 2.0;
     size_t need = (pidx ? 0 : index_bytes<T>(nr, occ)) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
                   align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);     // cell-ordered results
@@ -1069,6 +1115,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if ((rc = aalloc(ar, &rb, 1))) break;
         if ((rc = scratch_alloc(ar, job.sc, nq, rb->counters[0]))) break;
         job.d_ref_pts = dr; job.occ = occ; job.k = k; job.squared = squared;
+        job_rescale_setup(c, job, !pidx && restarts < 2, 1);
         if (row_out) { job.out_d = dd; job.out_i = di; }
         else {
             if ((rc = aalloc(ar, &job.out_d, (size_t)nq * k))) break;
@@ -1087,6 +1134,7 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
         if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
         if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
+        if (rc == 3) { rc = PCU_RETRY; break; }
         if (row_out) { if (rc > 0) tm.mark(2); }
         else if (rc == 1) { if ((rc = unpermute_enqueue(s, job, dd, di))) break; tm.mark(2); }
         else if (rc == 2) {       // the resolver rewrote only the tied queries' rows: restore just those
@@ -1104,7 +1152,16 @@ static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset
         if (st) { st->n_queries = nq; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 2); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
+    if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
+}
+template <typename T>
+static int knn_impl(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
+                    T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx = nullptr) {
+    for (int restarts = 0;; ++restarts) {          // (restarts: occupancy rescale, see kRescaleAbove)
+        const int rc = knn_attempt<T>(c, query, nq, dataset, nr, k, max_leaf, out_d, out_i, flags, stream, st, pidx, restarts);
+        if (rc != PCU_RETRY) return rc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ two-sided ops
@@ -1130,12 +1187,13 @@ struct PairState {
     T* res_v = nullptr; long long* res_ij = nullptr; double* res_s = nullptr;
     ResultBlock* rb = nullptr; CallBlock* cb = nullptr;
     bool two = true;
+    bool allow_rescale = true;                          // cleared on the last restart of a call (occupancy rescale)
     int fuse = FUSE_NONE; FuseTail<T> tail;             // fused attempt (tail: arguments of the launch that ends the call)
     int* tie_hit = nullptr;
 };
 template <typename T>
-static size_t pair_bytes(int64_t nx, int64_t ny, double occ, bool on_dev) {
-    size_t b = index_bytes<T>(nx, occ) + index_bytes<T>(ny, occ) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
+static size_t pair_bytes(int64_t nx, int64_t ny, double occ_x, double occ_y, bool on_dev) {
+    size_t b = index_bytes<T>(nx, occ_x) + index_bytes<T>(ny, occ_y) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
                align_up((size_t)nx * sizeof(T), 256) + align_up((size_t)ny * sizeof(T), 256) +
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
                6 * align_up((size_t)kRedBlocks * 8, 256) + 8192 +
@@ -1160,19 +1218,21 @@ static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, hipStream_t s2, Pa
 }
 template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
-                      bool squared, double occ, bool want_pos_x, bool want_pos_y, PairState<T>& P, Timer& tm,
+                      bool squared, double occ_x, double occ_y, bool want_pos_x, bool want_pos_y, PairState<T>& P, Timer& tm,
                       pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx, int fuse_mode = FUSE_NONE) {
     P.two = two_sided;
     P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = tie_order_xy; P.yx.tie_order = tie_order_yx;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
-    if (index_alloc(ar, ix, nx, occ, want_pos_x, true, use_one_pass(c)) || index_alloc(ar, iy, ny, occ, want_pos_y, true, use_one_pass(c))) return -1;
-    ix.src = P.dx; iy.src = P.dy; ix.occ_built = iy.occ_built = occ;        // (the jobs below hold copies: what a rebuild after a slot overflow starts from)
+    if (index_alloc(ar, ix, nx, occ_x, want_pos_x, true, use_one_pass(c)) || index_alloc(ar, iy, ny, occ_y, want_pos_y, true, use_one_pass(c))) return -1;
+    ix.src = P.dx; iy.src = P.dy; ix.occ_built = occ_x; iy.occ_built = occ_y;        // (the jobs below hold copies: what a rebuild after a slot overflow starts from)
     if (ix.bucketed && iy.bucketed && ix.one_pass != iy.one_pass) ix.one_pass = iy.one_pass = false;
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
-    P.xy.occ = P.yx.occ = occ; P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
+    P.xy.occ = occ_y; P.yx.occ = occ_x;            // a direction's occupancy is its dataset's
+    P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
+    job_rescale_setup(c, P.xy, P.allow_rescale, 1); job_rescale_setup(c, P.yx, P.allow_rescale, 0);
     if (aalloc(ar, &P.cb, 1)) return -1;
     P.rb = &P.cb->rb;
     if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
@@ -1208,8 +1268,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ, &iy, P.dy, occ, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
-    else if (index_build(ix, P.dx, occ, s, !c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ, s2, !c->eager_large)) return -1;
+    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
+    else if (index_build(ix, P.dx, occ_x, s, !c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ_y, s2, !c->eager_large)) return -1;
     if (s2 != s) {      // both searches need both indices
         HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
         HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
@@ -1248,6 +1308,14 @@ static bool fused_ok(const PairState<T>& P, const ResultBlock& h, bool tie_matte
     }
     return true;
 }
+// A fused attempt that failed on the balance check: restart at another grid resolution? (rescale_wanted updates the context)
+template <typename T>
+static bool fused_rescale(pcu_hip_ctx* c, hipStream_t s, const PairState<T>& P, const ResultBlock& h) {
+    bool want = false;
+    for (int d = 0; d < (P.two ? 2 : 1) && !want; ++d)
+        if (h.counters[d][C_SKEW]) want = rescale_wanted(c, d ? P.yx : P.xy, s);
+    return want;
+}
 // Redo a fused call's searches through the row-based path (everything the fused attempt left behind is reset).
 template <typename T>
 static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
@@ -1256,16 +1324,16 @@ static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, p
     if (st) { st->n_passes = 0; }
     return pair_search_enqueue(c, s, s, P, st);
 }
-// Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, <0 on error.
+// Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, 3 if the call is to be restarted, <0 on error.
 template <typename T>
 static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false) {
     if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
     else if (wait_result_block(c, s)) return -1;
     memcpy(host, c->h_pinned, sizeof(ResultBlock));
     int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
-    if (r1 < 0) return r1;
+    if (r1 < 0 || r1 == 3) return r1;
     int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1]) : 0;
-    if (r2 < 0) return r2;
+    if (r2 < 0 || r2 == 3) return r2;
     return (r1 | r2) ? 1 : 0;       // (2 = "only tied rows changed" matters to k_nearest_neighbors only)
 }
 
@@ -1295,6 +1363,7 @@ struct PendingPair {
     bool on_dev = false, squared = false, two_sided = true;
     unsigned flags = 0; int max_leaf = 10; pcu_hip_stats* st = nullptr;
     double p_norm = 2.0; int64_t *out_cxy = nullptr, *out_cyx = nullptr;      // chamfer
+    int restarts = 0;                       // how often this call has been restarted at another grid resolution (PCU_RETRY)
 };
 
 template <typename T>
@@ -1306,11 +1375,12 @@ static int hausdorff_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, i
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
-    const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
-    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
+    const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
+    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
+    pp.P.allow_rescale = pp.restarts < 2;
     pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
     pp.on_dev = on_dev; pp.squared = squared; pp.two_sided = two_sided; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
-    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ, false, false, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ_x, occ_y, false, false, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
     if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     return 0;
 }
@@ -1330,13 +1400,14 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
             if (fused_ok(P, host, tie_matters)) {
                 for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
-            } else if ((rc = unfuse_and_research(c, s, P, st))) break;
+            } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
         if (!done) {
             for (int attempt = 0; attempt < 2; ++attempt) {
                 if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
                 tm.mark(3);
-                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }   // syncs; 1 => redo epilogue
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
                 else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
@@ -1377,14 +1448,18 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
         if (st) { st->n_queries = two_sided ? pp.nx + pp.ny : pp.nx; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
+    if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
 template <typename T>
 static int hausdorff_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, bool two_sided, int max_leaf,
                           T* out_d, int64_t* out_i, int64_t* out_j, unsigned flags, void* stream, pcu_hip_stats* st) {
-    PendingPair<T> pp;
-    if (int rc = hausdorff_begin(c, x, nx, y, ny, two_sided, max_leaf, flags, stream, st, pp)) return rc;
-    return hausdorff_end(c, pp, out_d, out_i, out_j);
+    for (int restarts = 0;; ++restarts) {          // (restarts: occupancy rescale, see kRescaleAbove)
+        PendingPair<T> pp; pp.restarts = restarts;
+        if (int rc = hausdorff_begin(c, x, nx, y, ny, two_sided, max_leaf, flags, stream, st, pp)) return rc;
+        const int rc = hausdorff_end(c, pp, out_d, out_i, out_j);
+        if (rc != PCU_RETRY) return rc;
+    }
 }
 
 static int pcode_of(double p) {
@@ -1405,8 +1480,9 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
     if (st) memset(st, 0, sizeof *st);
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
-    const double occ = c->occupancy > 0 ? c->occupancy : default_occupancy(1);
-    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ, on_dev))) return PCU_HIP_ERR_RUNTIME;
+    const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
+    if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
+    pp.P.allow_rescale = pp.restarts < 2;
     pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
     pp.on_dev = on_dev; pp.two_sided = true; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
     pp.p_norm = p_norm; pp.out_cxy = out_cxy; pp.out_cyx = out_cyx;
@@ -1416,7 +1492,7 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
     // p = 2 without indices: the value is the sum of the nearest-neighbour distances -> fused epilogue, no result rows
     const int fuse = (p_norm == 2.0 && !out_cxy && !out_cyx) ? FUSE_SUM : FUSE_NONE;
-    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ, out_cxy != nullptr, out_cyx != nullptr, pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ_x, occ_y, out_cxy != nullptr, out_cyx != nullptr, pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
     if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     return 0;
 }
@@ -1436,7 +1512,8 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             if (fused_ok(P, host, false)) {
                 for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
-            } else if ((rc = unfuse_and_research(c, s, P, st))) break;
+            } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
         if (!done) {
             long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
@@ -1458,7 +1535,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                                    reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
                 HIP_TRY(hipGetLastError());
                 tm.mark(3);
-                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc <= 0) break; rc = 0; }
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }
                 else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
@@ -1474,14 +1551,18 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
         if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
     ctx_end(c);
+    if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
 template <typename T>
 static int chamfer_impl(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf, double* out_mean2,
                         int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st) {
-    PendingPair<T> pp;
-    if (int rc = chamfer_begin(c, x, nx, y, ny, p_norm, max_leaf, out_cxy, out_cyx, flags, stream, st, pp)) return rc;
-    return chamfer_end(c, pp, out_mean2);
+    for (int restarts = 0;; ++restarts) {
+        PendingPair<T> pp; pp.restarts = restarts;
+        if (int rc = chamfer_begin(c, x, nx, y, ny, p_norm, max_leaf, out_cxy, out_cyx, flags, stream, st, pp)) return rc;
+        const int rc = chamfer_end(c, pp, out_mean2);
+        if (rc != PCU_RETRY) return rc;
+    }
 }
 
 
@@ -1594,7 +1675,7 @@ static int batch_lanes(pcu_hip_ctx* c, int n_pairs, void* stream, unsigned flags
     while ((int)c->lanes.size() < want) {
         pcu_hip_ctx* l = nullptr;
         if (pcu_hip_ctx_create(c->device, &l)) return -1;
-        l->occupancy = c->occupancy;
+        l->occupancy = c->occupancy; l->occ_scale[0] = c->occ_scale[0]; l->occ_scale[1] = c->occ_scale[1];
         c->lanes.push_back(l);
     }
     for (pcu_hip_ctx* l : c->lanes) l->occupancy = c->occupancy;
@@ -1646,7 +1727,13 @@ static int batch_run(pcu_hip_ctx* c, int n_pairs, unsigned flags, void* stream, 
         for (int it = 0; it < mine + L; ++it) {
             const int lane = it % L;
             if (cur[lane] >= 0) {
-                const int r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
+                int r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
+                for (int restarts = 1; r == PCU_RETRY; ++restarts) {         // occupancy rescale: the lane's context has a new scale
+                    pend[lane] = PendingPair<T>(); pend[lane].restarts = restarts;
+                    pcu_hip_stats again;
+                    r = begin(c->lanes[l0 + lane], pend[lane], cur[lane], lflags, &again);
+                    if (!r) r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
+                }
                 if (r && !rc) { rc = r; err = g_err; }
                 { std::lock_guard<std::mutex> g(mu); stats_add(st, lst[lane]); }
                 cur[lane] = -1;

@@ -48,6 +48,8 @@ struct SearchArgs {
                                     // must not turn a wave into a millisecond-long pole
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then refits the dataset grid (pcu_hip.hip, search_finish)
+    float skew_lo;                  //      ... or when it is MORE even than this (sumsq < skew_lo; 0 = off): a grid kept finer than the default for
+                                    //      surface-like clouds met a cloud that fills its volume (pcu_hip.hip: rescale_wanted)
     const GridParams<T>* qgp;       // grid of the QUERY cloud: a pass gives up (flag word skew_flag[kLargeFlag] = the OR of both clouds'
                                     // GridParams::has_large) when either cloud's bucketed index is not ready: 1 = over-full buckets still
                                     // unplaced (the host runs k_bucket_large and repeats the pass -- the common case saves that launch),
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
     if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
 
@@ -403,7 +405,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
     if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
@@ -608,7 +610,7 @@ __device__ __forceinline__ void search1_bal_body(const SearchArgs<float>& a, con
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
     if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
     const int qpos = valid ? t0 + lane : nq - 1;            // padding lanes mirror the last query (no effect on the box)
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && (float)g.sumsq > a.skew_limit) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
     if (const int hl = g.has_large | a.qgp->has_large) { if (t0 == 0 && lane == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
@@ -970,8 +972,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     const int hl0 = a0.gp->has_large | a0.qgp->has_large, hl1 = a1.gp->has_large | a1.qgp->has_large;
     int total0 = (a0.qcount_dev ? v00 : a0.nq) + (a0.qlist2 ? v01 : 0);
     int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
-    if (a0.skew_limit > 0.f && (float)ss0 > a0.skew_limit) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
-    if (njobs > 1 && a1.skew_limit > 0.f && (float)ss1 > a1.skew_limit) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
+    if (a0.skew_limit > 0.f && ((float)ss0 > a0.skew_limit || (float)ss0 < a0.skew_lo)) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
+    if (njobs > 1 && a1.skew_limit > 0.f && ((float)ss1 > a1.skew_limit || (float)ss1 < a1.skew_lo)) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
     if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = hl0; total0 = 0; }
     if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = hl1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {

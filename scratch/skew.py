@@ -20,6 +20,11 @@ v = rng.normal(size=(n,3)); v /= np.linalg.norm(v,axis=1,keepdims=True); w = rng
 cases["sphere_surface"] = (v, w)
 a = rng.random((n,3)); a[0] = [1000,1000,1000]; b = rng.random((n,3)); b[0] = [-1000,-1000,-1000]
 cases["outlier_bbox"] = (a, b)
+G = os.path.join(ROOT, 'tests', 'golden'); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from conftest import mesh_samples
+bv = np.load(os.path.join(G, 'bunny_v.npy')).astype(np.float64); bf = np.load(os.path.join(G, 'bunny_f.npy'))
+cases["mesh_samples"] = (mesh_samples(bv, bf, n, seed=1), mesh_samples(bv, bf, n, seed=2))
+cases["uniform_again"] = cases["uniform"]
 sel = sys.argv[1:]
 for name, (x, y) in cases.items():
     if sel and name not in sel: continue

@@ -212,3 +212,25 @@ def test_one_pass_build_overflow_falls_back(pcu, oracle_kind):
     assert np.array_equal(i, i0) and np.array_equal(np.asarray(d).view(np.uint32), np.asarray(d0).view(np.uint32))
     assert abs(float(res["chamfer"][0]) - float(c0)) <= 1e-4 * float(c0) and float(res["chamfer"][0]) == float(res["chamfer"][1])
     assert tuple(res["hausdorff"]) == tuple(h0)
+
+
+@pytest.mark.gpu
+def test_surface_clouds_take_the_finer_grid_and_stay_exact(pcu, oracle_kind):
+    """Clouds sampled from a surface make the passes give up on the balance check and the call restarts on a finer grid, which the
+    context then keeps (pcu_hip.hip: rescale_wanted); a volume-filling cloud afterwards switches back. Every call along the way
+    returns the reference's neighbours."""
+    rng = np.random.default_rng(41)
+    def sphere(n):
+        v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v.astype(np.float32)
+    sx, sy = sphere(400_000), sphere(300_000)
+    ux, uy = rng.random((300_000, 3), dtype=np.float32), rng.random((300_000, 3), dtype=np.float32)
+    for x, y in ((sx, sy), (sx, sy), (ux, uy), (sx, uy), (ux, uy)):
+        d, i = pcu.k_nearest_neighbors(x, y, 1)
+        d0, i0 = oracle.k_nearest_neighbors(x, y, 1, kind=oracle_kind)
+        assert np.array_equal(i, i0) and np.array_equal(np.asarray(d).view(np.uint32), np.asarray(d0).view(np.uint32))
+        c, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)
+        c0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=oracle_kind)
+        assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(c) - float(c0)) <= 1e-4 * float(c0)
+        assert abs(float(pcu.chamfer_distance(x, y)) - float(c0)) <= 1e-4 * float(c0)
+        assert tuple(pcu.hausdorff_distance(x, y, return_index=True)) == tuple(oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind))
