@@ -479,7 +479,8 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
 template <typename T>
 static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
-    const int blocks = a.qcount_dev ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
+    // (fused calls: the fixed grid always -- the arg-max slots are one per wave of that grid)
+    const int blocks = (a.qcount_dev || a.fuse != FUSE_NONE) ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, blocks); break;
     switch (K) {
@@ -546,7 +547,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.qgp = j.qidx.gp;
     a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
-    a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k;
+    a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
     return a;
 }
 
@@ -921,6 +922,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         SearchArgs<T> b = base_args(j, ridx);
         b.qlist = cur; b.nq = n_left; b.R = R;
         b.unresolved = nxt; b.n_unresolved = j.sc.counters + C_SPARE; b.ties = j.sc.tt; b.n_ties = j.sc.counters + C_TT;
+        b.f_accum = j.fuse != FUSE_NONE;        // a fused call's stragglers (fused_continue): their share joins the accumulators
         if (launch_search_wave<T>(KL, b, s)) return -1;
         int left = 0;
         HIP_TRY(hipMemcpyAsync(&left, j.sc.counters + C_SPARE, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1301,9 +1303,9 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
 }
 // A fused attempt stands when nothing needs the row-based machinery (see the head of this section).
 template <typename T>
-static bool fused_ok(const PairState<T>& P, const ResultBlock& h, bool tie_matters) {
+static bool fused_ok(const PairState<T>& P, const ResultBlock& h, bool tie_matters, bool stragglers_done = false) {
     for (int d = 0; d < (P.two ? 2 : 1); ++d) {
-        if (h.counters[d][C_SKEW] || h.counters[d][C_LARGE] || h.counters[d][C_U2] > 0) return false;
+        if (h.counters[d][C_SKEW] || h.counters[d][C_LARGE] || (h.counters[d][C_U2] > 0 && !stragglers_done)) return false;
         if (tie_matters && P.fuse == FUSE_ARGMAX && h.pad[2 + d]) return false;
     }
     return true;
@@ -1315,6 +1317,33 @@ static bool fused_rescale(pcu_hip_ctx* c, hipStream_t s, const PairState<T>& P, 
     for (int d = 0; d < (P.two ? 2 : 1) && !want; ++d)
         if (h.counters[d][C_SKEW]) want = rescale_wanted(c, d ? P.yx : P.xy, s);
     return want;
+}
+// A fused attempt whose only flaw is that some queries are still uncertified after radius 2 (sparse tails, outliers): finish
+// those with the host-driven passes of search_finish -- in fused mode the wave-per-query kernel adds every query it certifies to
+// the direction's exact sum / arg-max slots -- and fold again. Returns 1 if the call is complete (host block refreshed), 0 if
+// the row-based path has to take over, < 0 on error.
+template <typename T>
+static int fused_continue(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock& host, bool tie_matters) {
+    static const bool off = getenv("PCU_HIP_NO_FUSED_CONTINUE") != nullptr;
+    if (off) return 0;
+    const int nd = P.two ? 2 : 1;
+    bool any = false;
+    for (int d = 0; d < nd; ++d) {
+        if (host.counters[d][C_SKEW] || host.counters[d][C_LARGE]) return 0;
+        any = any || host.counters[d][C_U2] > 0;
+    }
+    if (!any) return 0;                         // (a tied arg-max row: rows are needed)
+    for (int d = 0; d < nd; ++d) {
+        if (host.counters[d][C_U2] <= 0) { if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; } continue; }
+        const int r = search_finish(c, ar, s, d ? P.yx : P.xy, st, host.counters[d]);
+        if (r < 0) return r;
+    }
+    P.tail.seq = ++c->seq;
+    hipLaunchKernelGGL(k_fuse_tail<T>, dim3(1), dim3(kTailThreads), 0, s, P.tail);
+    HIP_TRY(hipGetLastError());
+    if (wait_result_block(c, s)) return -1;
+    memcpy(&host, c->h_pinned, sizeof host);
+    return fused_ok(P, host, tie_matters, /*stragglers_done=*/true) ? 1 : 0;
 }
 // Redo a fused call's searches through the row-based path (everything the fused attempt left behind is reset).
 template <typename T>
@@ -1401,6 +1430,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = fused_continue(c, ar, s, P, st, host, tie_matters)) != 0) { if (rc < 0) break; rc = 0; done = true; }
             else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
         if (!done) {
@@ -1513,6 +1543,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = fused_continue(c, ar, s, P, st, host, false)) != 0) { if (rc < 0) break; rc = 0; done = true; }
             else if ((rc = unfuse_and_research(c, s, P, st))) break;
         }
         if (!done) {

@@ -70,6 +70,8 @@ struct SearchArgs {
     // ... and the wave-per-query pass adds its few queries: FUSE_SUM exactly, into f_limbs / f_special (reduce.h: exact_add);
     // FUSE_ARGMAX one partial per wave in f_wave_v / f_wave_k[wave]. k_fuse_tail (reduce.h) folds everything.
     unsigned long long* f_limbs; double* f_special; T* f_wave_v; long long* f_wave_k;
+    int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
+                                    // slots instead of overwriting them
 };
 
 constexpr int kLargeFlag = 3;      // counters[C_LARGE] relative to counters[C_SKEW] (pcu_hip.hip)
@@ -961,6 +963,10 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     T fbv0 = -Limits<T>::max_v, fbv1 = -Limits<T>::max_v;
     long long fbk0 = 0x7fffffffffffffffll, fbk1 = 0x7fffffffffffffffll;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (a0.fuse == FUSE_ARGMAX && a0.f_accum) {        // (only the host-driven straggler passes of a fused call)
+        fbv0 = a0.f_wave_v[wave]; fbk0 = a0.f_wave_k[wave];
+        if (njobs > 1) { fbv1 = a1.f_wave_v[wave]; fbk1 = a1.f_wave_k[wave]; }
+    }
     const int nwaves = (n_blocks * kBlock) >> 6;       // (n_blocks = gridDim.x, as an argument: reading gridDim costs a fetch of the dispatch packet)
     // work items: job 0's list(s), then (two-sided calls) job 1's. This launch usually serves a few hundred queries, so its
     // time is its chain of dependent memory round trips; the six device words its prologue needs are therefore fetched
