@@ -12,7 +12,7 @@ ranks with no data-path collective (weak scaling); the per-step scalars are gath
 Prints ONE JSON line on rank 0 (contract in the task description): metric/value = whole-job query-points/s, plus
   roofline      dominant kernel k_search1_flat<float> (both directions in one launch): SURVEY 8d algorithmic bytes of the
                 Chamfer row (24 B per query-point) / HIP-event launch time vs the 8 TB/s HBM peak; measured HBM traffic and the
-                issue-side counters (VALU / SALU issue fraction, active lanes) come from profiles/hbm_traffic.json, which
+                issue-side counters (VALU busy, TA busy, SALU issue fraction, active lanes) come from profiles/hbm_traffic.json, which
                 profiles/postprocess.py derives from the round's rocprofv3 --pmc passes;
   cpu_baseline  the reference's nanoflann path on this box's host cores (median of 3; search-only seconds beside it);
   parity        the GPU result of the timed pair against the reference's result on the SAME arrays (value + both index arrays).
@@ -214,7 +214,9 @@ def main():
                 "whole_op": {"alg_bytes_per_step": 48.0 * n * world, "achieved_GBps": 48.0 * n * world / (dt / steps) / 1e9,
                              "frac": 48.0 * n * world / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
                              "note": "all launches of the step + host; SURVEY 8d: 2*3*4*(N+M) bytes"}}
-        for k in ("valu_issue_frac", "salu_issue_frac", "active_lane_frac", "valu_insts_per_wave", "salu_insts_per_wave", "counters_source"):
+        # what actually bounds the kernel (it is not HBM-bound and cannot be): VALU issue, with the vector-memory address path next
+        for k in ("valu_busy_frac", "ta_busy_frac", "salu_issue_frac", "active_lane_frac", "valu_insts_per_wave", "salu_insts_per_wave",
+                  "vmem_insts_per_wave", "valu_issue_frac_at_2_cycles", "counters_source"):
             if k in cnt:
                 roof[k] = cnt[k]
         out = {

@@ -9,7 +9,7 @@ G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 N_SIMD, N_CU = 1024, 256          # MI355X: 256 CUs x 4 SIMD-32
 line = [l for l in open(os.path.join(G, f"{tag}_bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
-db = glob.glob(os.path.join(G, f"{tag}_trace", "*", "*.db"))[0]
+db = max(glob.glob(os.path.join(G, f"{tag}_trace", "*", "*.db")), key=os.path.getmtime)      # (earlier collections may have left files: newest)
 txt = subprocess.run([sys.executable, os.path.join(P, "summarize_rocprof.py"), db], capture_output=True, text=True).stdout
 open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w").write(txt.replace(ROOT + "/", ""))
 
@@ -19,7 +19,7 @@ def pmc(prefix, d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not fs:
         return agg
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = r["Kernel_Name"].replace("void pcu::", "").split("(")[0].replace("pcu::", "")
         if k.startswith("k_"): agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
@@ -71,7 +71,7 @@ open(os.path.join(P, f"{tag}_pmc.txt"), "w").write("\n".join(out) + "\n")
 dom = [k for k in traffic if k.startswith("k_search1_flat<float")]
 rep = {"source": f"profiles/{tag}_pmc.txt", "counters_source": f"profiles/{tag}_pmc.txt + profiles/{tag}_calib.txt",
        "k_search1_flat_f32_bytes_per_launch": traffic[dom[0]] if dom else None,
-       "index_build_bytes_per_step": sum(v * (2 if k.startswith("k_bucket_sort") else 1) for k, v in traffic.items() if k.startswith(("k_bbox", "k_make_grid", "k_bucket"))),
+       "index_build_bytes_per_step": sum(v for k, v in traffic.items() if k.startswith(("k_bbox", "k_make_grid", "k_bucket"))),      # every pass is one launch for both clouds
        "note": "one launch = both directions of the 1M-vs-1M Chamfer step; calibrated FETCH_SIZE + WRITE_SIZE, see the header of the source file"}
 if dom:
     c = {k: mean(v) for k, v in sq[dom[0]].items()}
@@ -80,17 +80,20 @@ if dom:
     cyc = c.get("SQ_BUSY_CYCLES", 0.0) / 32.0 or c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     rep["kernel_cycles"] = cyc
     if cyc and c.get("SQ_INSTS_VALU"):
-        # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, wave scheduling); one scalar
-        # instruction per cycle per CU
-        rep["valu_issue_frac"] = 2.0 * c["SQ_INSTS_VALU"] / (N_SIMD * cyc)
-        rep["salu_issue_frac"] = c.get("SQ_INSTS_SALU", 0.0) / (N_CU * cyc)
         rep["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c.get("SQ_WAVES", 1.0)
         rep["salu_insts_per_wave"] = c.get("SQ_INSTS_SALU", 0.0) / c.get("SQ_WAVES", 1.0)
+        # "2 cycles per wave64 VALU instruction" (MI355X_MICROARCH.md, wave scheduling) is the best case; the instruction mix of the
+        # search kernels issues at 2.5-4.4 cycles (profiles/r02_ubench.txt), so this figure UNDERSTATES how busy the VALU is:
+        rep["valu_issue_frac_at_2_cycles"] = 2.0 * c["SQ_INSTS_VALU"] / (N_SIMD * cyc)
+        rep["salu_issue_frac"] = c.get("SQ_INSTS_SALU", 0.0) / (N_CU * cyc)     # one scalar instruction per cycle per CU
     if c.get("SQ_ACTIVE_INST_VALU"):
         rep["active_lane_frac"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        rep["valu_active_quadcycles_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc) if cyc else None
-    if c.get("SQ_INST_CYCLES_SALU") and cyc:
-        rep["salu_busy_frac"] = c["SQ_INST_CYCLES_SALU"] / (N_CU * cyc)
+        # SQ_ACTIVE_INST_VALU counts 4-cycle units (like SQ_WAVE_CYCLES: ACTIVE + WAIT_INST + WAIT = WAVE_CYCLES holds in these units)
+        rep["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc) if cyc else None
+    if c.get("TA_BUSY_avr") and cyc:
+        rep["ta_busy_frac"] = c["TA_BUSY_avr"] / cyc
+    if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_WAVES"):
+        rep["vmem_insts_per_wave"] = c["SQ_INSTS_VMEM_RD"] / c["SQ_WAVES"]
 json.dump(rep, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
 cfg = os.path.join(G, f"{tag}_configs.jsonl")
 if os.path.exists(cfg):

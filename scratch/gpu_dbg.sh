@@ -1,6 +1,7 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; export PYTHONUNBUFFERED=1
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
 python -c "import torch"
-timeout 300 python scratch/skew.py 2>&1 | grep -v amdgpu.ids | tail -9
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 300 python scratch/fuzz.py 2>&1 | tail -3
+for c in gauss_s0.05 outlier_bbox; do
+ (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/skew2_$c -- python $GRAFT_REPO_ROOT/scratch/skew.py $c > $GRAFT_REPO_ROOT/gpurun_out/skew2_$c.log 2>&1)
+ tail -1 gpurun_out/skew2_$c.log
+done
