@@ -1,5 +1,8 @@
 // csrc/sinkhorn.h -- dense pairwise distances and Sinkhorn iterations: the one dense N x M workload of the
-// path's neighbourhood, HBM-bound (every Sinkhorn iteration streams the (nb, m, n) cost matrix twice: 2 m n s bytes).
+// path's neighbourhood. Designated bound: HBM (an iteration needs the (nb, m, n) cost matrix for both updates: 2 m n s bytes when
+// read twice, m n s with k_sink_iter); measured, an iteration is bound by its arithmetic -- per element three IEEE divisions by eps
+// and two exp(), kept as the reference computes them -- at ~1.7 TB/s of algorithmic traffic, so halving the reads (k_sink_iter)
+// bought 2 %, and keeping the next row's loads in flight across the block reductions nothing more.
 //
 // Replaces point_cloud_utils/_sinkhorn.py (pure numpy in the reference):
 //   pairwise_distances :4-33    M[b,i,j] = || a[b,i,:] - b[b,j,:] ||_p   (numpy.linalg.norm(..., axis=-1, ord=p))
@@ -122,6 +125,72 @@ __global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s, T* __re
         part_mx[o] = M2; part_sum[o] = tot;
     }
 }
+// One launch per iteration for n <= 256 * CPT columns: the u update AND the column sums of the v update from ONE read of M.
+// A block owns `rows_per_block` consecutive rows of one batch; thread t owns the columns t, t + 256, ... (CPT of them). Per row:
+// the thread loads its CPT elements (coalesced), the block reduces max and sum of exp((-M + v) / eps) as k_sink_rows does and
+// gets the row's new u -- which is all the v update needs from that row (the reference updates v with the NEW u, :116-117) --
+// so the same registers go straight into the thread's running (max, sum) of exp((-M + u_new) / eps) for its columns. The
+// block's column partials are then merged over the blocks by k_sink_cols_finish. HBM traffic per iteration: m n s bytes for M
+// (half of the two-pass scheme) + 2 x the partials (n x blocks-per-batch x 2 s).
+// (The block reductions use a raw LDS barrier -- s_waitcnt lgkmcnt(0) + s_barrier, no fence on global memory -- so that the NEXT
+// row's loads, issued at the top of the trip, stay in flight across them: __syncthreads() would wait for every outstanding
+// vector-memory operation, and a block is a chain of row trips.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void k_sink_iter(const SinkArgs<T> s, T* __restrict__ part_mx, T* __restrict__ part_sum, int rows_per_block) {
+    if (*s.done) return;
+    __shared__ T s_red[2][2][4];           // [row parity][max / sum][wave]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slab = blockIdx.x, bt = blockIdx.y;
+    const int i0 = slab * rows_per_block, i1 = min(s.m, i0 + rows_per_block);
+    const T* Mb = s.M + (size_t)bt * s.m * s.n; const T* v = s.v + (size_t)bt * s.n;
+    T vj[CPT], cmx[CPT], cacc[CPT], mv[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { const int j = tid + 256 * k; vj[k] = j < s.n ? v[j] : (T)0; cmx[k] = -(T)INFINITY; cacc[k] = 0; }
+    if (i0 < i1) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const int j = tid + 256 * k; mv[k] = j < s.n ? Mb[(size_t)i0 * s.n + j] : (T)INFINITY; }
+    }
+    for (int i = i0; i < i1; ++i) {
+        T nx[CPT];                          // next row, requested now
+        const int in = min(i + 1, i1 - 1);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const int j = tid + 256 * k; nx[k] = j < s.n ? Mb[(size_t)in * s.n + j] : (T)INFINITY; }
+        const size_t o = (size_t)bt * s.m + i;
+        const T la = log(s.a[o]), uo = s.u[o];
+        T (&red)[2][4] = s_red[i & 1];
+        T mx = -(T)INFINITY;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const T x = (-mv[k] + vj[k]) / s.eps; mx = x > mx ? x : mx; }        // (a column past n: x = -inf)
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { const T w = __shfl_xor(mx, of, 64); mx = w > mx ? w : mx; }
+        if (lane == 0) red[0][wave] = mx;
+        lds_barrier();
+        mx = red[0][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mx = red[0][w] > mx ? red[0][w] : mx;
+        T acc = 0;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { const T x = (-mv[k] + vj[k]) / s.eps; acc += exp(x - mx); }
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) acc += __shfl_xor(acc, of, 64);
+        if (lane == 0) red[1][wave] = acc;
+        lds_barrier();
+        acc = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        const T un = s.eps * (la - (log(acc) + mx));
+        if (tid == 0) { const T d = uo - un; s.du[o] = d < 0 ? -d : d; s.u[o] = un; }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const T x = (-mv[k] + un) / s.eps;
+            if (x > cmx[k]) { cacc[k] = cacc[k] * exp(cmx[k] - x) + (T)1; cmx[k] = x; } else cacc[k] += exp(x - cmx[k]);
+            mv[k] = nx[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int j = tid + 256 * k;
+        if (j < s.n) { const size_t o = ((size_t)slab * s.nb + bt) * s.n + j; part_mx[o] = cmx[k]; part_sum[o] = cacc[k]; }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_sink_cols_finish(const SinkArgs<T> s, const T* __restrict__ part_mx, const T* __restrict__ part_sum, int n_slabs) {
     if (*s.done) return;
@@ -136,6 +205,34 @@ __global__ __launch_bounds__(256) void k_sink_cols_finish(const SinkArgs<T> s, c
     const T vn = s.eps * (log(s.b[o]) - lse);
     const T d = s.v[o] - vn;
     s.dv[o] = d < 0 ? -d : d; s.v[o] = vn;
+}
+// The same merge for many slabs (k_sink_iter: one per block of rows): a block owns 32 columns, its 32 thread rows stride over the
+// slabs with a streaming merge, then merge in LDS as k_sink_cols does.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sink_cols_merge(const SinkArgs<T> s, const T* __restrict__ part_mx, const T* __restrict__ part_sum, int n_slabs) {
+    if (*s.done) return;
+    __shared__ T s_mx[32][33], s_sum[32][33];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5, j = blockIdx.x * 32 + c, bt = blockIdx.y;
+    const size_t o = (size_t)bt * s.n + j, stride = (size_t)s.nb * s.n;
+    T mx = -(T)INFINITY, acc = 0;
+    if (j < s.n)
+        for (int k = r; k < n_slabs; k += 32) {
+            const T pm = part_mx[o + k * stride], ps = part_sum[o + k * stride];
+            if (pm == -(T)INFINITY) continue;
+            if (pm > mx) { acc = acc * exp(mx - pm) + ps; mx = pm; } else acc += ps * exp(pm - mx);
+        }
+    s_mx[r][c] = mx; s_sum[r][c] = acc;
+    __syncthreads();
+    if (r == 0 && j < s.n) {
+        T M2 = s_mx[0][c];
+        for (int k = 1; k < 32; ++k) M2 = s_mx[k][c] > M2 ? s_mx[k][c] : M2;
+        T tot = 0;
+        for (int k = 0; k < 32; ++k) tot += s_mx[k][c] == -(T)INFINITY ? (T)0 : s_sum[k][c] * exp(s_mx[k][c] - M2);
+        const T lse = log(tot) + M2;
+        const T vn = s.eps * (log(s.b[o]) - lse);
+        const T d = s.v[o] - vn;
+        s.dv[o] = d < 0 ? -d : d; s.v[o] = vn;
+    }
 }
 // err_u = max_b sum_i |du| , err_v likewise (:119-120); done when both are below the threshold (:122-123). One block.
 template <typename T>
