@@ -159,6 +159,9 @@ __device__ __forceinline__ void row_lower_bounds(const GridParams<T>& g, const P
     }
 }
 
+// x clamped to [lo, hi] (lo <= hi): the median of the three
+__device__ __forceinline__ float clamp3(float lo, float hi, float x) { return __builtin_amdgcn_fmed3f(lo, hi, x); }
+__device__ __forceinline__ double clamp3(double lo, double hi, double x) { return x < lo ? lo : (x > hi ? hi : x); }
 // Offer one candidate to a lane's K best (ascending d2, registers). Ties are only *detected* here: an equal d2 that
 // is rejected at the k-th slot, or an evicted element equal to the new k-th, raises `tie`.
 template <typename T, int K>
@@ -173,14 +176,18 @@ __device__ __forceinline__ void offer(const T d, const int id, T (&bd)[K], int (
     tie = tie || (d == bd[K - 1]);         // rejected (or about to tie with) the k-th
     if (d < bd[K - 1]) {
         const T ev = bd[K - 1];
+        // sorted insertion, the largest drops out: new bd[i] = d clamped to [bd[i-1], bd[i]] -- one v_med3 per slot for the distances;
+        // the row ids follow with the two compares that slot i shares with slot i-1
+        bool gi = true;                     // bd[K-1] > d
 #pragma unroll
         for (int i = K - 1; i > 0; --i) {
             const bool gm = bd[i - 1] > d;
-            const bool gi = bd[i] > d;
-            bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);
+            bd[i] = clamp3(bd[i - 1], bd[i], d);
             bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
+            gi = gm;
         }
-        if (bd[0] > d) { bd[0] = d; bi[0] = id; }
+        bi[0] = gi ? id : bi[0];
+        bd[0] = gi ? d : bd[0];
         if (ev == bd[K - 1] && ev != Limits<T>::max_v) tie = true;      // evicted one equals the new k-th
     }
 }
