@@ -1024,8 +1024,11 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             }
         };
         constexpr unsigned kHeavyRow = 256;        // a row with more candidates than this is scanned by the whole wave
-        for (int r0 = 0; r0 < nrows; r0 += 64) {
-            const int r = r0 + lane;
+        // (2R+1)^2 <= 32 rows (radius 1 and 2, i.e. nearly every query that gets here): two lanes per row, each takes half of it --
+        // the pass is a chain of dependent loads per lane, so halving the chain halves the query
+        const int sp = nrows <= 32 ? 2 : 1;
+        for (int r0 = 0; r0 < nrows; r0 += 64 / sp) {
+            const int r = r0 + (sp == 2 ? lane >> 1 : lane);
             unsigned s = 0, e = 0;
             if (r < nrows) {
                 const int cz = z0 + r / ny, cy = y0 + r % ny;
@@ -1033,23 +1036,25 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 s = a.cell_start[lo]; e = a.cell_start[lo + (x1 - x0 + 1)];
             }
             const bool heavy = e - s > kHeavyRow;
-            // light rows: one lane per row. Small K: four candidates per trip, their loads issued together (the pass is
-            // latency-bound); slots past the row's end are killed (+inf / NaN d2 never enters the list)
-            constexpr int kU = K <= 8 ? 4 : 1;
-            for (unsigned p = s; p < (heavy ? s : e); p += kU) {
+            unsigned ls = s, le = e;                // this lane's share of the row
+            if (sp == 2) { const unsigned mid = s + ((e - s + 1u) >> 1); if (lane & 1) ls = mid; else le = mid; }
+            // light rows. K <= 32: four candidates per trip, their loads issued together (the pass is
+            // latency-bound); slots past the share's end are killed (+inf / NaN d2 never enters the list)
+            constexpr int kU = K <= 32 ? 4 : 1;            // (K = 64, 128: the lists fill the register file)
+            for (unsigned p = ls; p < (heavy ? ls : le); p += kU) {
                 Pt4<T> cc[kU];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, e - 1u)];
+                for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, le - 1u)];
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     const Pt4<T>& c = cc[u];
                     const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                    take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= e), (int)c.idx);
+                    take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= le), (int)c.idx);
                 }
             }
             // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
             // lane keeps the best of its share, the rounds below merge the lanes' lists as for light rows
-            unsigned long long hm = __ballot(heavy);
+            unsigned long long hm = __ballot(heavy && (sp == 1 || !(lane & 1)));        // (once per row)
             while (hm) {
                 const int owner = __ffsll((long long)hm) - 1;
                 hm &= hm - 1;
