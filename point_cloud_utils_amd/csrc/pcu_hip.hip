@@ -67,6 +67,15 @@ struct pcu_hip_ctx {
     char* kd_ws = nullptr; size_t kd_ws_cap = 0, kd_ws_off = 0;
     struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[4];   // [type][with second planeSplit loop]
     bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
+    // Speculative tree top (kd_build_device, mode 1): a call whose predecessor needed the tie-order resolver starts the top levels of
+    // the tree -- which do not depend on which queries are tied -- on aux_stream while the searches run; the resolver adopts them.
+    struct KdSpec {
+        bool active = false;                  // a prefix for (pts, gp, m, leaf, with_ph2) is in flight or done and not yet adopted
+        bool pending = false;                 // ev_done recorded and not yet waited for by a later user of the workspace
+        const void* pts = nullptr; const void* gp = nullptr; int m = 0, leaf = 0; bool with_ph2 = false; int pairs_done = 0;
+        hipEvent_t ev_fork = nullptr, ev_init = nullptr, ev_done = nullptr;
+    } kd_spec;
+    bool kd_spec_hint = false;                // sticky: the last large k_nearest_neighbors call of this context had genuine ties
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
     unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
@@ -640,10 +649,18 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
 }
 
 // Exact ties: rebuild nanoflann's kd-tree on the GPU and re-run the tied queries through nanoflann's own
-// traversal (kd_order.h). Only called when the grid search reported genuine ties.
+// traversal (kd_order.h). Only called when the grid search reported genuine ties -- or ahead of need, see KdSpec.
+constexpr int kKdSpecPairs = 4;          // level pairs started early: the 8 top levels, which hold (nearly) all points whichever queries are tied
+constexpr int kKdSpecMinPoints = 262144;
 template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
-                           KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0) {
+                           KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0,
+                           bool speculative = false) {
+    // speculative: only the first kKdSpecPairs level pairs, on c->aux_stream behind the event c->kd_spec.ev_fork (recorded by the caller
+    // on its stream once gp is final), no host synchronisation; a later normal call for the same input continues from there.
+    pcu_hip_ctx::KdSpec& sp = c->kd_spec;
+    const hipStream_t s_caller = s;
+    if (speculative) s = c->aux_stream;
     b.leaf_max = leaf_max;
     b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
     // level lists only ever hold nodes with more than sub_max elements
@@ -680,17 +697,35 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // level are pure launch floor: the level graph is first replayed without them; if some node turns out to hold such
     // elements (device flag), the build is redone with them and the context remembers (duplicated points, lattices).
     int hcnt[16] = {0};
+    // whoever uses the workspace next waits for an earlier speculative prefix (adopted or not)
+    if (sp.pending) { HIP_TRY(hipStreamWaitEvent(s, sp.ev_done, 0)); sp.pending = false; }
+    bool adopt = !speculative && sp.active && sp.pts == (const void*)d_pts && sp.gp == (const void*)gp && sp.m == M && sp.leaf == leaf_max &&
+                 sp.with_ph2 == c->kd_need_ph2 && M > b.sub_max;
+    if (!speculative) sp.active = false;
+    (void)s_caller;
     for (int rebuild = 0; rebuild < 2; ++rebuild) {
     const bool with_ph2 = c->kd_need_ph2;
+    int pairs_done = 0;
+    if (adopt && rebuild == 0) {
+        // the top levels are there (built without regions of interest: complete); the regions apply from here on
+        pairs_done = sp.pairs_done;
+        static const bool no_roi = getenv("PCU_HIP_KD_FULL") != nullptr;
+        if (roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && !no_roi)
+            hipLaunchKernelGGL(k_kd_roi<T>, dim3(1), dim3(kKdMaxRoi), 0, s, roi_job->qidx.sorted, roi_job->sc.tt, n_tied, roi_job->out_d, roi_job->k,
+                               roi_job->squared ? 1 : 0, roi_job->row_out ? 1 : 0, roi, n_roi);
+    } else {
+    if (speculative) HIP_TRY(hipStreamWaitEvent(s, sp.ev_fork, 0));
     HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(int), s));
     // few tied queries: build only the part of the tree their traversals can touch (kd_order.h, KdBuild::roi)
     static const bool no_roi = getenv("PCU_HIP_KD_FULL") != nullptr;
-    if (roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && !no_roi)
+    if (!speculative && roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && !no_roi)
         hipLaunchKernelGGL(k_kd_roi<T>, dim3(1), dim3(kKdMaxRoi), 0, s, roi_job->qidx.sorted, roi_job->sc.tt, n_tied, roi_job->out_d, roi_job->k,
                            roi_job->squared ? 1 : 0, roi_job->row_out ? 1 : 0, roi, n_roi);
     else HIP_TRY(hipMemsetAsync(n_roi, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kd_init_elems<T>, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_pts, M, b.E);
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
+    if (speculative) HIP_TRY(hipEventRecord(sp.ev_init, s));          // the caller's buffers (points, grid parameters) are not read after this
+    }
     const int items_ub = (int)max_items;
     // One level = 9 short launches; the count of nodes per level lives on the device and kernels of an exhausted
     // level exit at once, so levels need no host decision. Two consecutive levels (the ping-pong of the level
@@ -726,7 +761,17 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
             G.key_ptr = (const void*)b.E; G.key_m = M; G.key_leaf = leaf_max;
         }
-        int pairs = (expected + 1) / 2;
+        if (speculative) {
+            static const int spec_pairs = getenv("PCU_HIP_KD_SPEC_PAIRS") ? atoi(getenv("PCU_HIP_KD_SPEC_PAIRS")) : kKdSpecPairs;
+            const int np = std::min(spec_pairs, (expected + 1) / 2);
+            for (int i = 0; i < np; ++i) { if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2); }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(sp.ev_done, s));
+            sp.active = true; sp.pending = true; sp.pts = (const void*)d_pts; sp.gp = (const void*)gp; sp.m = M; sp.leaf = leaf_max;
+            sp.with_ph2 = with_ph2; sp.pairs_done = np;
+            return 0;
+        }
+        int pairs = std::max(1, (expected + 1) / 2 - pairs_done);
         for (int guard = 0; guard < 100000; ++guard) {
             for (int i = 0; i < pairs; ++i) {
                 if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2);
@@ -738,6 +783,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             pairs = 1;
         }
     }
+    if (speculative) return 0;          // (a tree small enough for the LDS sub-tree kernel alone: nothing to start early)
     if (!with_ph2 && hcnt[9]) { c->kd_need_ph2 = true; continue; }
     break;
     }
@@ -767,8 +813,33 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     return 0;
 }
 
+// Start the tree's top levels ahead of need (see pcu_hip_ctx::KdSpec): called between a call's index build and its searches when the
+// context's previous large call had genuine ties. Costs GPU cycles, not wall time, when this call has none.
+template <typename T>
+static int kd_speculate(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const SearchJob<T>& j) {
+    static const bool off = getenv("PCU_HIP_NO_KD_SPEC") != nullptr;
+    if (off || !c->kd_spec_hint || !j.tie_order || j.ridx.n < kKdSpecMinPoints) return 0;
+    pcu_hip_ctx::KdSpec& sp = c->kd_spec;
+    if (!sp.ev_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&sp.ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&sp.ev_init, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sp.ev_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(sp.ev_fork, s));             // the dataset's grid parameters (bbox = the root's) are final
+    KdBuild<T> b; int* err = nullptr; int levels = 0;
+    return kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr, (const SearchJob<T>*)nullptr, 0, /*speculative=*/true);
+}
+// ... and, at the end of that call: the early kernels read the caller's points and the call's grid parameters -- both may be recycled once
+// the call returns -- so wait for them (long done by then); a prefix nobody adopted means the prediction was wrong.
+static void kd_speculate_end(pcu_hip_ctx* c, bool call_completed) {
+    pcu_hip_ctx::KdSpec& sp = c->kd_spec;
+    if (!sp.pending && !sp.active) return;
+    if (sp.ev_init) (void)hipEventSynchronize(sp.ev_init);
+    if (sp.active) { sp.active = false; if (call_completed) c->kd_spec_hint = false; }
+}
+
 template <typename T>
 static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, int n_tt, pcu_hip_stats* st) {
+    c->kd_spec_hint = j.ridx.n >= kKdSpecMinPoints;          // genuine ties: calls like this one will probably have them again
     hipEvent_t e0 = c->ev[4], e1 = c->ev[5];
     const bool timed = st && c->time_phases;
     if (timed) (void)hipEventRecord(e0, s);
@@ -1129,6 +1200,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
+        if ((rc = kd_speculate(c, ar, s, job))) break;
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
         if (row_out) { hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError()); }
         else if ((rc = unpermute_enqueue(s, job, dd, di, rb, c->h_pinned, ++c->seq))) break;   // optimistic: redone below if stragglers / ties remain
@@ -1153,6 +1225,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         HIP_TRY(hipStreamSynchronize(s));
         if (st) { st->n_queries = nq; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 2); collect_kernel_times(c, st); }
     } while (0);
+    kd_speculate_end(c, rc != PCU_RETRY);
     ctx_end(c);
     if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -1907,6 +1980,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (c->aux) (void)hipFree(c->aux);
     if (c->tickets) (void)hipFree(c->tickets);
     if (c->arena) (void)hipFree(c->arena);
+    for (hipEvent_t e : {c->kd_spec.ev_fork, c->kd_spec.ev_init, c->kd_spec.ev_done}) if (e) (void)hipEventDestroy(e);
     kd_graph_drop(c);
     if (c->kd_ws) (void)hipFree(c->kd_ws);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

@@ -234,3 +234,20 @@ def test_surface_clouds_take_the_finer_grid_and_stay_exact(pcu, oracle_kind):
         assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(c) - float(c0)) <= 1e-4 * float(c0)
         assert abs(float(pcu.chamfer_distance(x, y)) - float(c0)) <= 1e-4 * float(c0)
         assert tuple(pcu.hausdorff_distance(x, y, return_index=True)) == tuple(oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind))
+
+
+@pytest.mark.gpu
+def test_speculative_tree_top_keeps_tie_order(pcu, oracle_kind):
+    """After a large call with genuine ties the next one starts the top of nanoflann's tree on a second stream while the searches run
+    (pcu_hip.hip: kd_speculate) and the resolver adopts it. The calls before, with and after a speculation -- adopted, and wasted on a
+    cloud without ties -- all return the reference's rows."""
+    rng = np.random.default_rng(51)
+    y = rng.random((300_000, 3), dtype=np.float32)
+    y[1000:3000] = y[5000:7000]                          # duplicated rows: exact ties for every query near them
+    x = rng.random((200_000, 3), dtype=np.float32)
+    x[:500] = y[1000:1500]
+    y2 = rng.random((300_000, 3), dtype=np.float32)      # generic: no ties
+    for data, k in ((y, 4), (y, 4), (y2, 4), (y, 8), (y, 8)):
+        d, i = pcu.k_nearest_neighbors(x, data, k)
+        d0, i0 = oracle.k_nearest_neighbors(x, data, k, kind=oracle_kind)
+        assert np.array_equal(i, i0) and np.array_equal(np.asarray(d).view(np.uint32), np.asarray(d0).view(np.uint32))
