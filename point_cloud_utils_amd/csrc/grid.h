@@ -494,7 +494,10 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const BucketSide<T>
 // with the two-pass pipeline and keeps to it for this context (pcu_hip.hip: search_finish).
 template <typename T>
 __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __restrict__ pts, int n, GridParams<T>* gp, int shift, unsigned* fill,
-                                                   Pt4<T>* __restrict__ tmp, const unsigned cap) {
+                                                   Pt4<T>* __restrict__ tmp, const unsigned cap, long long* prof) {
+    // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
+    long long t_prev = prof ? wall_clock64() : 0;
+#define OP_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
     __shared__ unsigned s_cnt[kBkMaxBuckets];      // the block's count per bucket, then the slot position of its first record
     const GridParams<T>& g = *gp;
     const int NB = (g.ncells + (1 << shift) - 1) >> shift;
@@ -507,6 +510,7 @@ __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __re
         const int i = min(base + j * kBkThreads + (int)threadIdx.x, n - 1);
         px[j] = pts[3 * (size_t)i]; py[j] = pts[3 * (size_t)i + 1]; pz[j] = pts[3 * (size_t)i + 2];
     }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OP_PROF(0); }          // head: zero + point loads
     unsigned bk[kBkPts], rk[kBkPts];
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
@@ -515,6 +519,7 @@ __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __re
         rk[j] = count_rank(s_cnt, bk[j], valid);
     }
     __syncthreads();
+    OP_PROF(1);                                                                          // keys + LDS ranks
     for (int i = threadIdx.x; i < NB; i += kBkThreads) {
         const unsigned c = s_cnt[i];
         if (c) {
@@ -524,18 +529,21 @@ __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __re
         }
     }
     __syncthreads();
+    OP_PROF(2);                                                                          // slot reservations (global atomics)
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
         const int i = base + j * kBkThreads + (int)threadIdx.x;
         const unsigned pos = s_cnt[bk[j]] + rk[j];
         if (i < n && pos < (bk[j] + 1u) * cap) { Pt4<T> p; p.x = px[j]; p.y = py[j]; p.z = pz[j]; p.idx = i; tmp[pos] = p; }
     }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OP_PROF(3); if (threadIdx.x == 0) atomicAdd((unsigned long long*)&prof[7], 1ull); }   // stores
+#undef OP_PROF
 }
 template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass(const BucketSide<T> a0, const BucketSide<T> a1, int nb0) {
+__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass(const BucketSide<T> a0, const BucketSide<T> a1, int nb0, long long* prof) {
     const bool second = (int)blockIdx.x >= nb0;
     const BucketSide<T>& a = second ? a1 : a0;
-    bucket_onepass_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.tmp, a.cap);
+    bucket_onepass_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.tmp, a.cap, prof);
 }
 
 template <typename T>

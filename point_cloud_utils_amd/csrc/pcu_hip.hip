@@ -307,16 +307,27 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     if (nbs) {
         const BucketSide<T> s0 = bucket_side(*bs[0], bp[0]), s1 = nbs > 1 ? bucket_side(*bs[1], bp[1]) : s0;
         const int c0 = (bs[0]->n + kBkBlockPts - 1) / kBkBlockPts, c1 = nbs > 1 ? (bs[1]->n + kBkBlockPts - 1) / kBkBlockPts : 0;
-        const bool one_pass = bs[0]->one_pass;
-        if (one_pass) hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
-        else {
-            hipLaunchKernelGGL(k_bucket_count<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
-            hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
-        }
         static long long* prof = nullptr;       // PCU_HIP_PROF_BUILD: stage times of k_bucket_sort, printed per build (synchronises)
         static const bool do_prof = getenv("PCU_HIP_PROF_BUILD") != nullptr;
         if (do_prof && !prof) HIP_TRY(hipMalloc((void**)&prof, 8 * sizeof(long long)));
         if (do_prof) HIP_TRY(hipMemsetAsync(prof, 0, 8 * sizeof(long long), s));
+        const bool one_pass = bs[0]->one_pass;
+        if (one_pass) {
+            static long long* prof1 = nullptr;
+            if (do_prof && !prof1) HIP_TRY(hipMalloc((void**)&prof1, 8 * sizeof(long long)));
+            if (do_prof) HIP_TRY(hipMemsetAsync(prof1, 0, 8 * sizeof(long long), s));
+            hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0, do_prof ? prof1 : nullptr);
+            if (do_prof) {
+                long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof1, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+                const double nb = h[7] > 0 ? (double)h[7] : 1.0;
+                fprintf(stderr, "[onepass prof] blocks %lld | mean us per block: zero+loads %.2f  keys+LDS ranks %.2f  slot reservations %.2f  stores %.2f\n", h[7],
+                        h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0);
+            }
+        }
+        else {
+            hipLaunchKernelGGL(k_bucket_count<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+            hipLaunchKernelGGL(k_bucket_scatter<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0);
+        }
         const int t0 = bs[0]->nb_max, t1 = nbs > 1 ? bs[1]->nb_max : 0;
         const int cnt_cap = 1 << std::max(bs[0]->shift, nbs > 1 ? bs[1]->shift : 0);
         const size_t lds = bucket_sort_lds_bytes<T>(cnt_cap);
