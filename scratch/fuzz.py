@@ -43,6 +43,8 @@ for case in range(ncases):
             h = pcu.hausdorff_distance(q, r, return_index=True); h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
             ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True); ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=kind)
             ok = h == h0 and np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(ch) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30
+            # the fused calls (no indices asked for)
+            ok = ok and abs(float(pcu.chamfer_distance(q, r)) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30 and pcu.hausdorff_distance(q, r) == h0[0]
     except Exception as e:
         ok = False; tag += f" EXC {e!r}"
     if not ok:

@@ -1,9 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export PYTHONUNBUFFERED=1
 python -c "import torch"
-for v in 4 0 4 5 3; do
-PCU_HIP_KD_SPEC_PAIRS=$v timeout 200 python bench.py --config c3 --steps 8 --warmup 2 --no-parity --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'): d=json.loads(l); print('pairs=$v c3 %.3f ms' % d['ms_per_step'])"
-done
+for v in 4 2; do echo "COARSE_AT=$v"; PCU_HIP_COARSE_AT=$v timeout 200 python scratch/skew.py gauss_s0.05 outlier_bbox 2>&1 | grep -v amdgpu | tail -2; done
