@@ -666,7 +666,7 @@ constexpr int kKdSpecMinPoints = 262144;
 template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
                            KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0,
-                           bool speculative = false) {
+                           bool speculative = false, bool need_depth = true, int** max_depth_out = nullptr) {
     // speculative: only the first kKdSpecPairs level pairs, on c->aux_stream behind the event c->kd_spec.ev_fork (recorded by the caller
     // on its stream once gp is final), no host synchronisation; a later normal call for the same input continues from there.
     pcu_hip_ctx::KdSpec& sp = c->kd_spec;
@@ -799,9 +799,11 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     break;
     }
     (void)c;
-    // finish every small node inside one workgroup's LDS
-    HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // finish every small node inside one workgroup's LDS (the level loop's last read-back already holds the count)
+    if (!(M > b.sub_max)) {
+        HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     const int n_sub = hcnt[4];
     if (n_sub > 0) {
         static bool attr_set[2] = {false, false};
@@ -813,6 +815,8 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         hipLaunchKernelGGL(k_kd_subtree<T>, dim3(n_sub), dim3(kSubThreads), kd_sub_lds_bytes<T>(), s, b);
         HIP_TRY(hipGetLastError());
     }
+    if (max_depth_out) *max_depth_out = counters + 5;
+    if (!need_depth && !b.prof && !n_real_out) { *levels_out = 0; return 0; }      // (the caller sizes its stacks by a bound: one host round trip less)
     HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *levels_out = hcnt[5] + 1;      // tree depth (root = 0) + 1
@@ -857,8 +861,14 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
     // attempt 0: tree restricted to the tied queries' regions of interest (few ties); attempt 1: the whole tree, if a
     // traversal wanted to walk into a big unbuilt part (rare; results are exact either way, this is about time)
     for (int attempt = 0; attempt < 2; ++attempt) {
-        KdBuild<T> b; int* err = nullptr; int levels = 0;
-        if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr, attempt == 0 ? &j : nullptr, n_tt)) return -1;
+        KdBuild<T> b; int* err = nullptr; int levels = 0; int* depth_dev = nullptr;
+        // few tied queries: their traversal stacks are sized by a bound on the tree depth instead of waiting for the exact one
+        // (a deeper tree raises the traversal's error flag 1: the traversal alone is then repeated with the exact depth)
+        constexpr int kDepthBound = 96;
+        const bool lazy = n_tt <= 4096;
+        if (kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr, attempt == 0 ? &j : nullptr, n_tt,
+                            false, /*need_depth=*/!lazy, &depth_dev)) return -1;
+        if (lazy) levels = kDepthBound;
         KdSearchArgs<T> a;
         a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
         a.k = j.k; a.squared = j.squared ? 1 : 0; a.row_out = j.row_out ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
@@ -872,6 +882,18 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         int herr = 0;
         HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (herr == 1 && lazy) {            // deeper than the bound: once more with the exact depth
+            int depth = 0;
+            HIP_TRY(hipMemcpy(&depth, depth_dev, sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemsetAsync(err, 0, sizeof(int), s));
+            a.stack_cap = depth + 3;
+            if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
+            a.stack = frames;
+            hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         if (herr == 2 && attempt == 0) continue;
         if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
         break;
