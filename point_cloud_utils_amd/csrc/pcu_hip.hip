@@ -565,7 +565,10 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
     a.skew_limit = 0.f; a.skew_lo = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.qgp = j.qidx.gp;
-    a.lane_max_cand = (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
+    // unbalanced clouds (finer sub-box levels exist): a lane next to a heavy cell would scan thousands of candidates serially and hold its
+    // wave for hundreds of microseconds (10 % cluster cloud: the base-grid lane pass took 380 us for 0.9M queries) -- hand such queries to
+    // the wave-per-query pass, which scans heavy rows with 64 lanes
+    a.lane_max_cand = j.n_fine > 0 ? (unsigned)std::max(384.0, 6.0 * 27.0 * j.occ) : (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
     return a;

@@ -271,6 +271,16 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
     if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    // A closed sub-box level (dense part of an unbalanced cloud) can never certify a query outside its box [org, org + G h) --
+    // face_lower_bound is then at most the query's distance to the level's points, which no candidate beats -- so such a query goes to
+    // the next level without a scan (most queries of the call, when the box is a small cluster).
+    if (g.closed) {
+        const T tx = (q.x - g.org[0]) * g.inv_h, ty = (q.y - g.org[1]) * g.inv_h, tz = (q.z - g.org[2]) * g.inv_h;
+        if (!(tx >= (T)0 && tx < (T)Gx && ty >= (T)0 && ty < (T)Gy && tz >= (T)0 && tz < (T)Gz)) {      // (skipping a level is always safe)
+            wave_append(true, qpos, a.unresolved, a.n_unresolved);
+            return;
+        }
+    }
 
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);

@@ -1,8 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export PYTHONUNBUFFERED=1
 python -c "import torch"
-timeout 200 python bench.py --config c3 --steps 8 --warmup 2 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'): d=json.loads(l); print('c3 %.3f ms' % d['ms_per_step'], json.dumps(d.get('parity'))[:60])"
-timeout 250 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu -k "lattice or tie or kd or dup or speculative or beyond" 2>&1 | tail -2
+timeout 200 python scratch/skew.py mix_10pct_cluster gauss_s0.05 outlier_bbox mesh_samples 2>&1 | grep -v amdgpu | tail -5
+timeout 250 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu -k "unbalanced or refit or overflow or config5 or surface" 2>&1 | tail -2
+timeout 100 python scratch/fuzz.py 7 40 2>&1 | tail -1
