@@ -993,13 +993,19 @@ __global__ __launch_bounds__(kBlock) void k_heavy_partial(const T* __restrict__ 
 template <typename T>
 __global__ void k_heavy_finish(const GridParams<T>* __restrict__ gp, const T* __restrict__ pbox, const double* __restrict__ pcnt, int nparts,
                                double occ, double cap, QuantState<T>* out, double* out_target) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave (launched with 64 threads): the lanes stride over the partials, then fold (counts are integers held in doubles: exact)
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double C = 0, Q = 0;
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
-    for (int b = 0; b < nparts; ++b) {
+    for (int b = threadIdx.x; b < nparts; b += 64) {
         C += pcnt[2 * b]; Q += pcnt[2 * b + 1];
         for (int j = 0; j < 3; ++j) { const T a = pbox[b * 6 + j], c = pbox[b * 6 + 3 + j]; lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j]; }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { C += __shfl_xor(C, o, 64); Q += __shfl_xor(Q, o, 64); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { lo[j] = wave_min(lo[j]); hi[j] = wave_max(hi[j]); }
+    if (threadIdx.x != 0) return;
     double cells_in_box = 1;
     for (int j = 0; j < 3; ++j) {
         T a = lo[j], b = hi[j];
