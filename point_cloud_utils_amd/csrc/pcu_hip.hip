@@ -471,7 +471,7 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
         // PCU_HIP_BAL=1 (float): the balanced variant (search.h: search1_bal_body; item = record << 6 | lane, hence the size limit).
-        // Opt-in: measured on MI355X it runs 7.7 instead of ~20 loop trips per wave and a third fewer gather instructions, but
+        // Opt-in: measured on MI355X it runs 7.7 instead of ~13.7 group trips per wave and a third fewer gather instructions, but
         // as many VALU instructions (1344 vs 1260 per wave), and VALU issue is what bounds both: 84-87 us against 82-83 us.
         static const bool want_bal = getenv("PCU_HIP_BAL") != nullptr;
         const bool bal = sizeof(T) == 4 && want_bal && a.n_ref < (1u << 26) && p2.a[1].n_ref < (1u << 26);
