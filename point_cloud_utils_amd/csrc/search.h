@@ -593,7 +593,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
 // Balanced variant of the k = 1 main pass (float). Measured on MI355X (profiles/ubench/ta_rate.hip): a per-lane gather
 // instruction occupies the CU's texture-address path for ~17-21 cycles whatever its width (8/12/16 B) and HOWEVER FEW
 // LANES ARE ACTIVE (2 of 64: 21 cycles); k_search1_flat's 71 vector-memory instructions per wave x ~19 cycles are its
-// run time (TA busy 80 %), and its per-lane run loop executes max-over-lanes trips at ~30 % active lanes. Here the lanes
+// run time (TA busy 80 %), and its per-lane run loop executes max-over-lanes trips at ~40 % active lanes. Here the lanes
 // only scan their own centre row; the surviving cut runs of the other eight rows are cut into groups of 4 records and
 // pooled in a per-wave LDS queue, which the 64 lanes then consume TOGETHER, 64 groups per trip, whoever's they are:
 //   item   = (first record of the group) << 6 | owner lane                               [4 bytes]
