@@ -162,6 +162,9 @@ static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
     }
     c->arena_off = 0;
     c->n_kev = 0;
+    // debugging: poison the workspace (PCU_HIP_DEBUG_POISON=<byte>) so that reads of memory no kernel of this call wrote show up
+    static const int poison = getenv("PCU_HIP_DEBUG_POISON") ? atoi(getenv("PCU_HIP_DEBUG_POISON")) : -1;
+    if (poison >= 0 && c->arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipMemset(c->arena, poison, c->arena_cap)); HIP_TRY(hipDeviceSynchronize()); }
     return 0;
 }
 // Sum of the bracketed main-search kernel durations of this call (valid after the final stream sync).
@@ -942,6 +945,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     // (one D2H copy + one stream sync for the whole call in the common case)
     int hc_redo[C_N], hc_large[C_N];
     bool redone = false;
+    if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[finish] role=%d n=%d occ=%.3f may=%d skew=%d large=%d u1=%d u2=%d t1=%d\n", j.role, j.ridx.n, j.occ, (int)j.may_rescale, hc[C_SKEW], hc[C_LARGE], hc[C_U1], hc[C_U2], hc[C_T1]);
     if (hc[C_LARGE]) {
         // Every pass gave up at once because an index was not ready (GridParams::has_large).
         if (hc[C_LARGE] & 2) {
@@ -1516,6 +1520,7 @@ static int hausdorff_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, i
     const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
     pp.P.allow_rescale = pp.restarts < 2;
+    if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[pair begin] restarts=%d nx=%lld ny=%lld occ_x=%.3f occ_y=%.3f\n", pp.restarts, (long long)nx, (long long)ny, occ_x, occ_y);
     pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
     pp.on_dev = on_dev; pp.squared = squared; pp.two_sided = two_sided; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
     int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ_x, occ_y, false, false, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
@@ -1622,6 +1627,7 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
     pp.P.allow_rescale = pp.restarts < 2;
+    if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[pair begin] restarts=%d nx=%lld ny=%lld occ_x=%.3f occ_y=%.3f\n", pp.restarts, (long long)nx, (long long)ny, occ_x, occ_y);
     pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
     pp.on_dev = on_dev; pp.two_sided = true; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
     pp.p_norm = p_norm; pp.out_cxy = out_cxy; pp.out_cyx = out_cyx;
@@ -1993,6 +1999,7 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     DeviceGuard dg(device);
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
+    if (const char* e = getenv("PCU_HIP_OCC_SCALE")) { double a = 1, b = 1; if (sscanf(e, "%lf,%lf", &a, &b) == 2) { c->occ_scale[0] = a; c->occ_scale[1] = b; } }   // (debugging: start from given scales)
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

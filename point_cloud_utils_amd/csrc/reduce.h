@@ -68,8 +68,10 @@ __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, 
         for (int i = threadIdx.x; i < nb; i += kBlock) argmax_combine(a, ai, peek(&pv[off + i]), peek(&pi[off + i]));
         block_argmax(a, ai);
         if (threadIdx.x == 0) {
+            // (no row took part -- every distance NaN, e.g. the rows of a pass that gave up were never written -- : no index to read)
+            const long long pos = ai & 0xffffffffll;
             out_v[side] = a; out_ij[2 * side] = ai >> 32;
-            out_ij[2 * side + 1] = (side ? s1.corr : s0.corr)[ai & 0xffffffffll];
+            out_ij[2 * side + 1] = pos < (long long)(side ? s1.n : s0.n) ? (side ? s1.corr : s0.corr)[pos] : -1ll;
         }
     }
     if (threadIdx.x == 0) { *ticket = 0u; wait_stores(); }

@@ -8,6 +8,7 @@ import oracle
 kind = "ref" if oracle.have_ref() else "port"
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # (to replay a tail of a sweep)
 
 def make(rng, n, dist, dtype):
     if dist == "uniform": a = rng.random((n, 3))
@@ -26,7 +27,7 @@ def make(rng, n, dist, dtype):
 dists = ["uniform", "plane", "line", "clusters", "dups", "lattice", "offset", "aniso", "sphere", "mixed"]
 bad = 0
 t0 = time.time()
-for case in range(ncases):
+for case in range(first, ncases):
     rng = np.random.default_rng(seed0 * 1000 + case)
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     big = rng.random() < 0.5
@@ -35,15 +36,22 @@ for case in range(ncases):
     dq, dr = rng.choice(dists), rng.choice(dists)
     q, r = make(rng, n, dq, dtype), make(rng, m, dr, dtype)
     tag = f"case {case}: {dtype.__name__} n={n} m={m} k={k} q={dq} r={dr}"
+    if os.environ.get("FUZZ_VERBOSE"): print(tag, flush=True)
     try:
+        V = bool(os.environ.get('FUZZ_VERBOSE'))
+        if V: print('  knn', flush=True)
         d, c = pcu.k_nearest_neighbors(q, r, k)
+        if V: print('  knn done', pcu.last_stats(), flush=True)
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
         ok = np.array_equal(c, c0) and np.array_equal(d.view(np.uint8), d0.view(np.uint8))
         if k == 1 and ok:
+            if V: print('  hausdorff', flush=True)
             h = pcu.hausdorff_distance(q, r, return_index=True); h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
+            if V: print('  chamfer idx', flush=True)
             ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True); ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=kind)
             ok = h == h0 and np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(ch) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30
             # the fused calls (no indices asked for)
+            if V: print('  fused', flush=True)
             ok = ok and abs(float(pcu.chamfer_distance(q, r)) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30 and pcu.hausdorff_distance(q, r) == h0[0]
     except Exception as e:
         ok = False; tag += f" EXC {e!r}"
