@@ -251,3 +251,38 @@ def test_speculative_tree_top_keeps_tie_order(pcu, oracle_kind):
         d, i = pcu.k_nearest_neighbors(x, data, k)
         d0, i0 = oracle.k_nearest_neighbors(x, data, k, kind=oracle_kind)
         assert np.array_equal(i, i0) and np.array_equal(np.asarray(d).view(np.uint32), np.asarray(d0).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_poisoned_workspace_on_passes_that_give_up(pcu, oracle_kind, tmp_path):
+    """A pass that gives up (balance check: refit or occupancy rescale) leaves its result rows unwritten, and the epilogues enqueued behind
+    it must not follow what they find there (k_argmax_pair once read corr[0xffffffff] when every distance was NaN). The workspace is
+    filled with 0xff before every call (PCU_HIP_DEBUG_POISON, a child process: the switch is read once) and a small uneven pair --
+    a plane against a cloud with a tight cluster -- goes through every k = 1 op; results are the reference's."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(12015)
+    x = rng.random((922, 3)).astype(np.float32); x[:, 2] = 0.25
+    y = np.concatenate([rng.random((815, 3)), rng.normal(0.5, 0.001, (271, 3))]).astype(np.float32)
+    np.save(tmp_path / "x.npy", x); np.save(tmp_path / "y.npy", y)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
+        "x = np.load(%r); y = np.load(%r)\n"
+        "out = {}\n"
+        "for rep in range(2):\n"
+        "    d, i = pcu.k_nearest_neighbors(x, y, 1)\n"
+        "    h = pcu.hausdorff_distance(x, y, return_index=True); h1 = pcu.hausdorff_distance(y, x, return_index=True)\n"
+        "    c, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)\n"
+        "    c2 = pcu.chamfer_distance(x, y); h2 = pcu.hausdorff_distance(x, y)\n"
+        "np.savez(%r, d=d, i=i, h=np.array(h, dtype=np.float64), h1=np.array(h1, dtype=np.float64), c=np.float64(c), cxy=cxy, cyx=cyx, c2=np.float64(c2), h2=np.float64(h2))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "x.npy"), str(tmp_path / "y.npy"), str(tmp_path / "out.npz"))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PCU_HIP_DEBUG_POISON="255"), timeout=600)
+    got = np.load(tmp_path / "out.npz")
+    d0, i0 = oracle.k_nearest_neighbors(x, y, 1, kind=oracle_kind)
+    assert np.array_equal(got["i"], i0) and np.array_equal(got["d"].view(np.uint32), np.asarray(d0).view(np.uint32))
+    assert tuple(got["h"]) == tuple(np.array(oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind), dtype=np.float64))
+    assert tuple(got["h1"]) == tuple(np.array(oracle.hausdorff_distance(y, x, return_index=True, kind=oracle_kind), dtype=np.float64))
+    c0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=oracle_kind)
+    assert np.array_equal(got["cxy"], cxy0) and np.array_equal(got["cyx"], cyx0)
+    assert abs(float(got["c"]) - float(c0)) <= 1e-4 * float(c0) and abs(float(got["c2"]) - float(c0)) <= 1e-4 * float(c0)
+    assert float(got["h2"]) == float(got["h"][0])
