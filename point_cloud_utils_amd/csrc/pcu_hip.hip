@@ -676,7 +676,6 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // speculative: only the first kKdSpecPairs level pairs, on c->aux_stream behind the event c->kd_spec.ev_fork (recorded by the caller
     // on its stream once gp is final), no host synchronisation; a later normal call for the same input continues from there.
     pcu_hip_ctx::KdSpec& sp = c->kd_spec;
-    const hipStream_t s_caller = s;
     if (speculative) s = c->aux_stream;
     b.leaf_max = leaf_max;
     b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
@@ -719,7 +718,6 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     bool adopt = !speculative && sp.active && sp.pts == (const void*)d_pts && sp.gp == (const void*)gp && sp.m == M && sp.leaf == leaf_max &&
                  sp.with_ph2 == c->kd_need_ph2 && M > b.sub_max;
     if (!speculative) sp.active = false;
-    (void)s_caller;
     for (int rebuild = 0; rebuild < 2; ++rebuild) {
     const bool with_ph2 = c->kd_need_ph2;
     int pairs_done = 0;
