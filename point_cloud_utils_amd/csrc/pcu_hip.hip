@@ -1673,8 +1673,8 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
                 if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
                 // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
-                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx, P.xy.sc.counters + C_SKEW},
-                                   sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby, P.yx.sc.counters + C_SKEW};
+                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx, P.xy.sc.counters + C_SKEW, (long long)ny},
+                                   sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby, P.yx.sc.counters + C_SKEW, (long long)nx};
                 hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
                                    reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
                 HIP_TRY(hipGetLastError());

@@ -235,7 +235,9 @@ enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
 // device-to-host copy kernel behind them.
 template <typename T>
 struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; const T* d; int n; int nb;
-                   const int* giveup; };      // the direction's skew / unplaced-buckets flags: no rows exist (yet) when one is set
+                   const int* giveup;         // the direction's skew / unplaced-buckets flags: no rows exist (yet) when one is set
+                   long long n_tgt; };        // rows of tgt: a correspondence outside [0, n_tgt) is an unwritten row (a straggler whose
+                                              // result comes with the host-driven passes; this launch is then repeated) and is not followed
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, const PnormSide<T> s1, int pcode, double p, double* partial,
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
         if (pcode == P_TWO) {
             v = sd.d[i];
         } else {
-            const long long c = sd.corr[i];
+            long long c = sd.corr[i];
+            if ((unsigned long long)c >= (unsigned long long)sd.n_tgt) c = 0;          // (see PnormSide::n_tgt)
             const Pt4<T> q = sd.qsorted[i];
             const T a = sd.tgt[3 * c] - q.x, b = sd.tgt[3 * c + 1] - q.y, e = sd.tgt[3 * c + 2] - q.z;
             const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;

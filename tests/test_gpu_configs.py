@@ -286,3 +286,18 @@ def test_poisoned_workspace_on_passes_that_give_up(pcu, oracle_kind, tmp_path):
     assert np.array_equal(got["cxy"], cxy0) and np.array_equal(got["cyx"], cyx0)
     assert abs(float(got["c"]) - float(c0)) <= 1e-4 * float(c0) and abs(float(got["c2"]) - float(c0)) <= 1e-4 * float(c0)
     assert float(got["h2"]) == float(got["h"][0])
+    # ... and a general-norm Chamfer on clouds with sparse tails: the first epilogue launch runs before the stragglers' rows exist and must
+    # not follow what it finds in them (0x7f7f... = a huge row index)
+    g1 = rng.normal(0.5, 0.05, (40_000, 3)).astype(np.float32); g2 = rng.normal(0.5, 0.05, (30_000, 3)).astype(np.float32)
+    np.save(tmp_path / "g1.npy", g1); np.save(tmp_path / "g2.npy", g2)
+    code2 = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
+        "a = np.load(%r); b = np.load(%r)\n"
+        "for rep in range(2): v = [float(pcu.chamfer_distance(a, b, p_norm=p)) for p in (1, 3, np.inf)]\n"
+        "np.save(%r, np.array(v))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "g1.npy"), str(tmp_path / "g2.npy"), str(tmp_path / "v.npy"))
+    subprocess.run([sys.executable, "-c", code2], check=True, env=dict(os.environ, PCU_HIP_DEBUG_POISON="127"), timeout=600)
+    v = np.load(tmp_path / "v.npy")
+    for got_v, p in zip(v, (1, 3, np.inf)):
+        v0 = float(oracle.chamfer_distance(g1, g2, p_norm=p, kind=oracle_kind))
+        assert abs(got_v - v0) <= 1e-4 * v0
