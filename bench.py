@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per cloud (default: the headline 1M)")
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5", "normals", "morton", "voxel", "sinkhorn"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier", "normals", "morton", "voxel", "sinkhorn"])
     ap.add_argument("--pairs", type=int, default=32, help="c4: pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -280,21 +280,58 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
             d, c = pcu.k_nearest_neighbors(tq, tr, k)
             d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
             return {"idx_equal": bool(np.array_equal(c.cpu().numpy(), c0)), "dist_bits_equal": bool(np.array_equal(d.cpu().numpy(), d0)), "stats": pcu.last_stats()}
+    elif cfg == "c1":          # BASELINE config 1: the reference's CPU path on two 10k fp64 clouds is the expected result; the GPU call is timed
+        n = 10_000
+        x, y = cloud(1000 + 2 * rank, n, np.float64), cloud(1001 + 2 * rank, n, np.float64)
+        tx, ty = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        step = lambda: pcu.chamfer_distance(tx, ty)
+        units, alg = 2 * n, 2 * 3 * 8 * 2 * n
+        name = f"chamfer_distance, {n}-vs-{n} fp64 (reference CPU path = expected value)"
+        def check():
+            t0 = time.perf_counter(); ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=kind); t_cpu = time.perf_counter() - t0
+            ch, cxy, cyx = pcu.chamfer_distance(tx, ty, return_index=True)
+            return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
+                    "chamfer_rel": abs(float(ch) - float(ch0)) / float(ch0), "tol": 1e-6, "cpu_reference_seconds": t_cpu,
+                    "cpu_reference_value": 2 * n / t_cpu}
     elif cfg == "c4":
+        # 32 pairs per GPU; pair p of the job's npairs x world pairs belongs to rank p mod world (batched.shard_pairs) and goes through
+        # batched_hausdorff: the library's batch entry point per rank + the job's ONE all_gather of the scalars, inside the timed region
         npairs, n = args.pairs, 262144
-        pairs = [(torch.from_numpy(cloud(1000 + 2 * (rank * npairs + p), n, np.float32)).to(dev),
-                  torch.from_numpy(cloud(1001 + 2 * (rank * npairs + p), n, np.float32)).to(dev)) for p in range(npairs)]
+        total = npairs * world
         from point_cloud_utils_amd import batched
-        step = lambda: batched._map_chunks("hausdorff", lambda p: pairs[p], list(range(npairs)), 3)
+        pairs = {p: (torch.from_numpy(cloud(1000 + 2 * p, n, np.float32)).to(dev), torch.from_numpy(cloud(1001 + 2 * p, n, np.float32)).to(dev))
+                 for p in batched.shard_pairs(total, rank, world)}
+        step = lambda: batched.batched_hausdorff(lambda p: pairs[p], total)
         units, alg = npairs * 2 * n, npairs * 2 * 3 * 4 * 2 * n
-        name = f"hausdorff_distance, {npairs} independent {n}-vs-{n} fp32 pairs per GPU (batch entry point)"
+        name = f"hausdorff_distance, {npairs} independent {n}-vs-{n} fp32 pairs per GPU (batched_hausdorff: batch entry point + one all_gather)"
         def check():
             rows = step()
             ok = True
-            for p in range(min(2, npairs)):
+            for p in sorted(pairs):          # every pair of this rank against the reference
                 h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
                 ok &= tuple(rows[p]) == tuple(float(v) for v in h0)
-            return {"pairs_checked": min(2, npairs), "tuples_equal": bool(ok)}
+            return {"pairs_checked": len(pairs), "tuples_equal": bool(ok)}
+    elif cfg in ("gauss", "cluster", "outlier"):      # uneven clouds: Chamfer 1M-vs-1M fp32
+        n = 1_000_000
+        def make(seed):
+            rng = np.random.default_rng(seed)
+            if cfg == "gauss":
+                return rng.normal(0.5, 0.05, (n, 3)).astype(np.float32)
+            if cfg == "cluster":
+                return np.concatenate([rng.random((n * 9 // 10, 3)), rng.normal(0.5, 0.002, (n // 10, 3))]).astype(np.float32)
+            a = rng.random((n, 3)).astype(np.float32); a[7] = [60.0, -40.0, 25.0]
+            return a
+        x, y = make(1000 + 2 * rank), make(1001 + 2 * rank)
+        tx, ty = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        step = lambda: pcu.chamfer_distance(tx, ty)
+        units, alg = 2 * n, 48 * n
+        name = {"gauss": "chamfer_distance, 1M-vs-1M fp32 Gaussian sigma = 0.05", "cluster": "chamfer_distance, 1M-vs-1M fp32, 10 % of each cloud in a tight cluster (sigma 0.002)",
+                "outlier": "chamfer_distance, 1M-vs-1M fp32 uniform with one far outlier (bbox x 60)"}[cfg]
+        def check():
+            ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=kind)
+            ch, cxy, cyx = pcu.chamfer_distance(tx, ty, return_index=True)
+            return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
+                    "chamfer_rel": abs(float(step()) - float(ch0)) / float(ch0), "tol": 1e-4, "stats": pcu.last_stats()}
     elif cfg == "normals":          # 1M-point sheet, k = 16
         n, k = 1_000_000, 16
         rng = np.random.default_rng(9 + rank)
@@ -388,10 +425,10 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         if not args.no_parity:
             parity = check()
         steps = max(args.steps, 1)
-        unit = "query-points/s" if cfg in ("c2", "c3", "c4", "c5") else ("elements*iterations/s" if cfg == "sinkhorn" else "points/s")
+        unit = "query-points/s" if cfg in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier") else ("elements*iterations/s" if cfg == "sinkhorn" else "points/s")
         out = {"metric": f"{unit}, {name}", "value": units * world * steps / dt, "unit": unit, "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64" if cfg == "c5" else ("i32" if cfg == "morton" else "f32"), "data": "synthetic",
+               "vs_baseline": None, "dtype": "f64" if cfg in ("c1", "c5") else ("i32" if cfg == "morton" else "f32"), "data": "synthetic",
                "config": {"workload": name + ", inputs resident in HBM", "baseline_config": cfg},
                "roofline": {"bound": "hbm", "achieved": alg / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_step": alg,

@@ -26,6 +26,29 @@ def _ord_value(p):
     return float(p)
 
 
+def _promote_pair(a, b):
+    """numpy's result type of `a - b` for the dtypes the reference meets: float32 stays float32 only against float32 (or float16)."""
+    from . import _dtype_name, _is_torch
+    want = "float32" if all(_dtype_name(x) in ("float32", "float16") for x in (a, b)) else "float64"
+    out = []
+    for x in (a, b):
+        if _dtype_name(x) != want:
+            if _is_torch(x):
+                import torch
+                x = x.to(torch.float32 if want == "float32" else torch.float64)
+            else:
+                x = np.asarray(x).astype(np.float32 if want == "float32" else np.float64)
+        out.append(x)
+    return out
+
+
+def _expand(x, shape):
+    from . import _is_torch
+    if tuple(x.shape) == tuple(shape):
+        return x
+    return x.expand(*shape) if _is_torch(x) else np.broadcast_to(x, shape)
+
+
 def pairwise_distances(a, b, p=None):
     """
     Compute the (batched) pairwise distance matrix between a and b which both have size [m, n, d] or [n, d]. The result is a tensor of size [m, n, n] (or [n, n]) whose entry [m, i, j] contains the distance_tensor between a[m, i, :] and b[m, j, :].
@@ -48,10 +71,16 @@ def pairwise_distances(a, b, p=None):
         raise ValueError("Invalid shape for a. Must be [m, n, d] or [n, d] but got", a.shape)
     if len(b.shape) != 3:
         raise ValueError("Invalid shape for a. Must be [m, n, d] or [n, d] but got", b.shape)
-    if _dtype_name(a) != _dtype_name(b):
-        raise ValueError(f"a and b must have the same dtype, got {_dtype_name(a)} and {_dtype_name(b)}")
-    if a.shape[0] != b.shape[0] or a.shape[2] != b.shape[2]:
-        raise ValueError(f"operands could not be broadcast together with shapes {tuple(a.shape)} {tuple(b.shape)}")
+    # the reference is one numpy expression (_sinkhorn.py:30-32): `a[:, :, None, :] - b[:, None, :, :]` broadcasts a batch of 1 against m and
+    # d = 1 against d, and promotes integer / mixed inputs as numpy does (int -> float64, float32 with float64 -> float64)
+    for ax in (0, 2):
+        if a.shape[ax] != b.shape[ax] and 1 not in (a.shape[ax], b.shape[ax]):
+            raise ValueError(f"operands could not be broadcast together with shapes {tuple(a.shape)} {tuple(b.shape)}")
+    nb_, d_ = max(a.shape[0], b.shape[0]), max(a.shape[2], b.shape[2])
+    if a.shape[0] == 0 or b.shape[0] == 0: nb_ = 0
+    if a.shape[2] == 0 or b.shape[2] == 0: d_ = 0
+    a, b = _promote_pair(a, b)
+    a = _expand(a, (nb_, a.shape[1], d_)); b = _expand(b, (nb_, b.shape[1], d_))
     (a, b), (ctx, flags, stream, t, tdev), suf, npd = _prep([a, b])
     nb, m, d = (int(x) for x in a.shape); n = int(b.shape[1])
     out = _empty((nb, m, n), npd, t, tdev)

@@ -56,7 +56,15 @@ __device__ __forceinline__ bool take_ticket(unsigned* ticket, unsigned nblocks) 
 #ifndef PCU_BBOX_BLOCKS
 #define PCU_BBOX_BLOCKS 256
 #endif
-constexpr int kBboxBlocks = PCU_BBOX_BLOCKS;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz
+constexpr int kBboxBlocks = PCU_BBOX_BLOCKS;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz (finite values only), [6] = non-finite flags
+constexpr int kBboxStride = 8;                 // values per partial
+// Non-finite coordinates (k_bbox_partial -> GridParams::nonfinite). The bounding box -- hence the grid -- is laid over the FINITE values;
+// points with a non-finite coordinate sit in border cells (cell_coord clamps) and their d2 is +inf or NaN, which never beats a
+// neighbour (strict '<' against a k-th best that starts at FLT_MAX): exactly what the reference's result set does with them
+// (nanoflann.hpp:1563 `dist < worst_dist`, :182). What the reference does NOT survive is a kd-tree built over NaN bounds: a NaN in
+// the dataset, or +inf and -inf along one axis ((low + high) / 2 = NaN, nanoflann.hpp:1090), make its traversal prune arbitrarily
+// and its rows depend on the tree. Those inputs are rejected (kNfNaN / kNfBothInf -> ValueError), see pcu_hip.hip: search_finish.
+constexpr int kNfNaN = 1, kNfBothInf = 2, kNfAnyInf = 4;
 
 // pts: row-major (n,3). Lane i reads 3 consecutive scalars at 3*i: a wave covers one contiguous 768 B
 // (f32) span with three strided dword loads, all of whose sectors are consumed. No atomics: every block
@@ -67,6 +75,8 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
                                           unsigned* __restrict__ zero2, int n_zero2, const int bid, const int nblk) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+    unsigned nf = 0;          // bit 0: NaN seen; bits 1..3: +inf on axis j; bits 4..6: -inf on axis j
+    auto classify = [&](T v, int j) { nf |= v != v ? 1u : (v > (T)0 ? (2u << j) : (16u << j)); };
     // four points = 12 consecutive scalars = three 16-byte (f32) loads per trip, all in flight together; a plain
     // point-per-trip loop waits for memory 15 times per thread at n = 1M
     struct __attribute__((packed, aligned(4))) Vec4 { T v[4]; };
@@ -76,10 +86,17 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
         const Vec4* p = reinterpret_cast<const Vec4*>(pts + 12 * (size_t)gi);
         const Vec4 a = p[0], b = p[1], c = p[2];
         const T v[12] = {a.v[0], a.v[1], a.v[2], a.v[3], b.v[0], b.v[1], b.v[2], b.v[3], c.v[0], c.v[1], c.v[2], c.v[3]};
+        bool all_fin = true;
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            lo[k % 3] = v[k] < lo[k % 3] ? v[k] : lo[k % 3];
-            hi[k % 3] = v[k] > hi[k % 3] ? v[k] : hi[k % 3];
+            const bool fin = (v[k] < (T)0 ? -v[k] : v[k]) <= Limits<T>::max_v;      // false for NaN and +-inf
+            all_fin = all_fin && fin;
+            lo[k % 3] = (fin && v[k] < lo[k % 3]) ? v[k] : lo[k % 3];
+            hi[k % 3] = (fin && v[k] > hi[k % 3]) ? v[k] : hi[k % 3];
+        }
+        if (!all_fin) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) if (!((v[k] < (T)0 ? -v[k] : v[k]) <= Limits<T>::max_v)) classify(v[k], k % 3);
         }
     }
     if (gtid < (n & 3)) {
@@ -87,8 +104,10 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             T v = pts[3 * (size_t)i + j];
-            lo[j] = v < lo[j] ? v : lo[j];
-            hi[j] = v > hi[j] ? v : hi[j];
+            const bool fin = (v < (T)0 ? -v : v) <= Limits<T>::max_v;
+            if (!fin) classify(v, j);
+            lo[j] = (fin && v < lo[j]) ? v : lo[j];
+            hi[j] = (fin && v > hi[j]) ? v : hi[j];
         }
     }
     {   // zero-fill (16-byte stores; `counts` is 256-byte aligned arena memory)
@@ -99,19 +118,30 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
         for (int i = gtid; i < n_zero2; i += gstride) zero2[i] = 0u;
     }
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    __shared__ unsigned s_nf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         T a = wave_min(lo[j]), b = wave_max(hi[j]);
         if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = b; }
     }
+    {
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) if (__ballot((nf >> b) & 1u)) m |= 1u << b;
+        if (lane == 0) s_nf[wave] = m;
+    }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int j = threadIdx.x;
         T a = s_lo[0][j], b = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { a = s_lo[w][j] < a ? s_lo[w][j] : a; b = s_hi[w][j] > b ? s_hi[w][j] : b; }
-        publish(&partial[bid * 6 + j], a);              // (agent-scope stores: k_bbox_grid's last block reads them in the same launch)
-        publish(&partial[bid * 6 + 3 + j], b);
+        publish(&partial[bid * kBboxStride + j], a);
+        publish(&partial[bid * kBboxStride + 3 + j], b);
+    } else if (threadIdx.x == 3) {
+        unsigned m = 0;
+        for (int w = 0; w < kBlock / 64; ++w) m |= s_nf[w];
+        publish(&partial[bid * kBboxStride + 6], (T)m);       // (<= 127: exact in T)
     }
 }
 
@@ -133,30 +163,44 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const BboxSide<T> a0, c
 template <typename T>
 __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel, double h_want = 0.0) {
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    __shared__ unsigned s_nf[kBlock / 64];
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
         T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
-        for (int b = threadIdx.x; b < nparts; b += kBlock)
+        unsigned nf = 0;
+        for (int b = threadIdx.x; b < nparts; b += kBlock) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T a = peek(&partial[b * 6 + j]), c = peek(&partial[b * 6 + 3 + j]);
+                T a = peek(&partial[b * kBboxStride + j]), c = peek(&partial[b * kBboxStride + 3 + j]);
                 lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
             }
+            nf |= (unsigned)peek(&partial[b * kBboxStride + 6]);
+        }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             T a = wave_min(lo[j]), c = wave_max(hi[j]);
             if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = c; }
         }
+        unsigned m = 0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) if (__ballot((nf >> b) & 1u)) m |= 1u << b;
+        if (lane == 0) s_nf[wave] = m;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    {
+        unsigned m = 0;
+        for (int w = 0; w < kBlock / 64; ++w) m |= s_nf[w];
+        const unsigned pinf = (m >> 1) & 7u, ninf = (m >> 4) & 7u;
+        gp->nonfinite = ((m & 1u) ? kNfNaN : 0) | ((pinf & ninf) ? kNfBothInf : 0) | ((pinf | ninf) ? kNfAnyInf : 0);
+    }
     if (sentinel) for (int j = 0; j < 8; ++j) { sentinel[j].x = sentinel[j].y = sentinel[j].z = (T)INFINITY; sentinel[j].idx = 0x7fffffff; }   // records n..n+7: see k_search / k_search1
     double ext[3];
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];
         for (int w = 1; w < kBlock / 64; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
-        if (!(lo <= hi)) { lo = 0; hi = 0; }      // all-NaN column
+        if (!(lo <= hi)) { lo = 0; hi = 0; }      // no finite value in this column
         gp->gmin[j] = lo; gp->gmax[j] = hi;
         ext[j] = (double)hi - (double)lo;
     }
@@ -244,26 +288,6 @@ __global__ __launch_bounds__(kBlock) void k_count(const T* __restrict__ pts, int
         if (s_key[k] != 0xffffffffu) s_base[k] = atomicAdd(&counts[s_key[k]], s_cnt[k]);
     __syncthreads();
     if (i < n) rank[i] = c != 0xffffffffu ? s_base[slot] + lr : 0u;
-}
-
-// k_bbox_partial + k_make_grid in ONE launch (opt-in, PCU_HIP_FUSED_GRID=1; measured slower than the two launches, see
-// index_build_pair): the block of a side that takes the side's last ticket folds the partials and lays out the grid (publish /
-// peek / relaxed ticket, no __threadfence). tickets: two zero-initialised words owned by the context, reset by the folding block.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_bbox_grid(const BboxSide<T> a0, const BboxSide<T> a1, int nb0, const GridSide<T> g0, const GridSide<T> g1, unsigned* tickets) {
-    const bool second = (int)blockIdx.x >= nb0;
-    const BboxSide<T>& a = second ? a1 : a0;
-    const int nblk = second ? (int)gridDim.x - nb0 : nb0;
-    bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, nblk);
-    __shared__ bool s_last;
-    wait_stores();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = take_ticket(&tickets[second ? 1 : 0], (unsigned)nblk);
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) tickets[second ? 1 : 0] = 0u;
-    const GridSide<T>& g = second ? g1 : g0;
-    make_grid_body<T>(g.gp, g.partial, g.nparts, g.n, g.occupancy, g.max_cells, g.sentinel, g.h_want);
 }
 
 // ---- exclusive scan over `counts[0..m)` in place; counts[m] receives the total -------------------------
@@ -950,7 +974,7 @@ __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, 
         gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
     }
     gp->ncells = G[0] * G[1] * G[2];
-    gp->sumsq = 0ull; gp->closed = closed; gp->has_large = 0;
+    gp->sumsq = 0ull; gp->closed = closed; gp->has_large = 0; gp->nonfinite = base->nonfinite;
 }
 
 // Heavy part of an indexed cloud: bounding box (+1 cell) and number of the points that sit in cells holding more than

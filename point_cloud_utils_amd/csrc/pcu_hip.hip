@@ -16,8 +16,6 @@
 #include <vector>
 #include <chrono>
 #include <atomic>
-#include <mutex>
-#include <thread>
 
 #include "../../include/pcu_hip.h"
 #include "grid.h"
@@ -228,7 +226,7 @@ template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
     size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8) * 4, 256) + align_up((size_t)(n + 8) * sizeof(Pt4<T>), 256) +
-               2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * 6 * sizeof(T), 256);
+               2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * kBboxStride * sizeof(T), 256);
     int sh = 0, nb = 0;
     if (bucket_plan(n, occ, &sh, &nb))
         b += align_up(std::max((size_t)n, (size_t)nb * kLargeBucket) * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
@@ -245,7 +243,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
-    if (aalloc(a, &g.bbox_partial, (size_t)kBboxBlocks * 6)) return -1;
+    if (aalloc(a, &g.bbox_partial, (size_t)kBboxBlocks * kBboxStride)) return -1;
     g.n_zero = g.max_cells + 1;
     if (g.bucketed) {
         g.bucket_total = g.cell_start + g.max_cells + 1; g.n_large = g.bucket_total + g.nb_max; g.n_zero = g.max_cells + 1 + g.nb_max + 1;
@@ -292,16 +290,10 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
         const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n, a.h_want};
         const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n, b->h_want} : g0;
-        // One launch for both (k_bbox_grid, last block lays out the grid) is opt-in: measured on MI355X at 2 x 1M points it takes
-        // 16.7 us against 8.1 + 4.9 us for the two launches (the folding block's chain of round trips -- ticket, 512 partials, the
-        // serial layout -- is longer than a launch boundary), step 0.187 vs 0.184 ms.
-        static const bool fused = getenv("PCU_HIP_FUSED_GRID") != nullptr;
-        if (tickets && fused) {
-            hipLaunchKernelGGL(k_bbox_grid<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks, g0, g1, tickets);
-        } else {
-            hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
-            hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
-        }
+        // (bbox + grid layout in ONE launch -- the last block folding the partials -- was measured in round 2: 16.7 us against
+        // 8.1 + 4.9 us for the two launches; removed)
+        hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
+        hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
     }
     // bucketed sides share their launches; a side too small / too coarse for buckets takes the atomic passes
     const GridIndex<T>* bs[2]; const T* bp[2]; int nbs = 0;
@@ -340,15 +332,9 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
             attr_set[sizeof(T) == 4 ? 0 : 1] = true;
         }
-        // One launch for both clouds, like the other passes. (With 512-thread blocks / 2048-point buckets the sort was faster as one
-        // launch per cloud -- 2 x 15.6 us against 39 us; with 1024 threads / 4096-point buckets all blocks of both clouds are
-        // resident at once and the shared launch wins: step 0.174 vs 0.186 ms. PCU_HIP_SPLIT_SORT=1 restores the split.)
-        static const bool split_sort = getenv("PCU_HIP_SPLIT_SORT") != nullptr;
-        if (split_sort && nbs > 1) {
-            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0), dim3(kSortThreads), lds, s, s0, s0, t0, do_prof ? prof : nullptr, cnt_cap);
-            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t1), dim3(kSortThreads), lds, s, s1, s1, t1, do_prof ? prof : nullptr, cnt_cap);
-        } else
-            hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
+        // One launch for both clouds, like the other passes (1024 threads / 4096-point buckets: all blocks of both clouds are
+        // resident at once; measured 0.174 vs 0.186 ms per step against one launch per cloud).
+        hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
         if (do_prof) {
             long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
             const double nb = h[7] > 0 ? (double)h[7] : 1.0;
@@ -430,7 +416,7 @@ static double default_occupancy(int k) {
     return std::max(2.0, (k + 3.0 * sqrt((double)k)) / 3.7);
 }
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
-constexpr int kMaxKLane = 64;       // lane-per-query register slots
+constexpr int kMaxKLane = 32;       // lane-per-query register slots (K = 64 needs 203-275 VGPRs: those k go wave-per-query from the start)
 constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
 constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
 constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
@@ -455,7 +441,6 @@ constexpr int kWaveBlocks = PCU_WAVE_BLOCKS;    // fixed grid of the wave-cooper
 
 // whole-call index builds use the one-pass bucket scatter until a cloud of this context overflows a slot (PCU_HIP_TWO_PASS=1: never)
 static bool use_one_pass(const pcu_hip_ctx* c) { static const bool off = getenv("PCU_HIP_TWO_PASS") != nullptr; return !off && !c->two_pass; }
-static bool use_gather_kernels() { static const bool v = getenv("PCU_HIP_TILE") == nullptr; return v; }
 static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }
 static int grid8(int nwork, int tb) { return (((nwork + tb - 1) / tb) + 7) / 8 * 8; }       // multiple of 8: XCD-aware block map
 
@@ -465,21 +450,13 @@ template <typename T>
 static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStream_t s, bool open_index,
                               const SearchArgs<T>* a1 = nullptr, int nwork1 = 0) {
     if (nwork <= 0) return 0;
-    // Default: the per-lane gather kernels; PCU_HIP_TILE=1 selects the LDS-tiled kernel (one wave per block). Measured on
-    // MI355X (profiles/r01_search_kernel_ab.txt): the tile kernel issues 15x fewer vector memory instructions but more
-    // VALU/SALU/LDS bookkeeping and is slower (129 vs 83 us at 1M/k=1), so gather stays default.
-    const bool use_gather = use_gather_kernels();
-    const int tb = use_gather ? kBlock : 64;
-    if (K == 1 && use_gather && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
+    // (Rejected variants, measured on MI355X in rounds 1-2 and removed from the tree: a one-wave-per-block LDS-tiled kernel, 129 vs 83 us
+    // at 1M / k = 1, profiles/r01_search_kernel_ab.txt; a per-wave work-queue variant of the k = 1 pass, 84-87 vs 82-83 us, profiles/r02_ubench.txt.)
+    const int tb = kBlock;
+    if (K == 1 && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
-        // PCU_HIP_BAL=1 (float): the balanced variant (search.h: search1_bal_body; item = record << 6 | lane, hence the size limit).
-        // Opt-in: measured on MI355X it runs 7.7 instead of ~13.7 group trips per wave and a third fewer gather instructions, but
-        // as many VALU instructions (1344 vs 1260 per wave), and VALU issue is what bounds both: 84-87 us against 82-83 us.
-        static const bool want_bal = getenv("PCU_HIP_BAL") != nullptr;
-        const bool bal = sizeof(T) == 4 && want_bal && a.n_ref < (1u << 26) && p2.a[1].n_ref < (1u << 26);
-#define PCU_FLAT(FUSE) do { if (bal) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE, true>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); \
-                            else hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE, false>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); } while (0)
+#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
         else if (a.fuse == FUSE_ARGMAX) PCU_FLAT(FUSE_ARGMAX);
         else PCU_FLAT(FUSE_NONE);
@@ -489,10 +466,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     }
     if (a1) return fail(PCU_HIP_ERR_RUNTIME, "internal: paired main pass without the k = 1 kernel");
     dim3 grid(grid8(nwork, tb)), block(tb);
-#define PCU_CASE(KK) case KK: if (use_gather) hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); \
-                              else hipLaunchKernelGGL((k_search_tile<T, KK>), grid, block, 0, s, a); break;
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
-        PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32) PCU_CASE(64)
+        PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
     }
 #undef PCU_CASE
@@ -548,6 +524,8 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     int n_tt = 0;                               // genuine-tie queries found (filled by search_finish)
     bool skew_check = true;                     // give up early on a badly unbalanced dataset grid (then: refitted finer grids)
     double skew_hi = kSkewFactor, skew_lo = 0.0; // ... thresholds on sumsq / n / (occ + 1); rescale: see kRescaleAbove
+    int bad_r = kNfNaN | kNfBothInf, bad_q = 0;  // non-finite input this operator rejects (grid.h: kNf*): k_nearest_neighbors takes any query and every
+                                                 // dataset the reference's kd-tree survives; the two-sided metrics reject all non-finite input
     bool may_rescale = false; int role = 1;      // role: which cloud of the call the dataset is (pcu_hip_ctx::occ_scale)
     GridIndex<T> fine[2]; int n_fine = 0;       // finer dataset grids for the dense parts, finest first (unbalanced clouds only)
     T* out_d = nullptr; long long* out_i = nullptr;
@@ -574,6 +552,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.lane_max_cand = j.n_fine > 0 ? (unsigned)std::max(384.0, 6.0 * 27.0 * j.occ) : (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
+    a.bad_r = j.bad_r; a.bad_q = j.bad_q;
     return a;
 }
 
@@ -633,7 +612,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 // (each direction keeps its own lists and counters). Falls back to two search_enqueue calls when a direction does not
 // take the k = 1 lane kernel (few queries, tile / generic kernels selected by environment).
 template <typename T>
-static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_gather_kernels() && use_k1_kernel(); }
+static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_k1_kernel(); }
 template <typename T>
 static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st) {
     if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
@@ -777,8 +756,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             G.key_ptr = (const void*)b.E; G.key_m = M; G.key_leaf = leaf_max;
         }
         if (speculative) {
-            static const int spec_pairs = getenv("PCU_HIP_KD_SPEC_PAIRS") ? atoi(getenv("PCU_HIP_KD_SPEC_PAIRS")) : kKdSpecPairs;
-            const int np = std::min(spec_pairs, (expected + 1) / 2);
+            const int np = std::min(kKdSpecPairs, (expected + 1) / 2);
             for (int i = 0; i < np; ++i) { if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2); }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(sp.ev_done, s));
@@ -933,6 +911,14 @@ static bool rescale_wanted(pcu_hip_ctx* c, const SearchJob<T>& j, hipStream_t s)
     return false;
 }
 
+// Non-finite input an operator does not take (grid.h: kNf*; search.h: index_not_ready): a ValueError on the Python side.
+static int nonfinite_error(bool metric) {
+    if (metric) return fail(PCU_HIP_ERR_INVALID, "Invalid input: the point clouds contain non-finite coordinates (NaN or inf). The reference pairs such rows through "
+                            "index -1 (numpy's last row), which is not a distance; chamfer_distance / hausdorff_distance reject them.");
+    return fail(PCU_HIP_ERR_INVALID, "Invalid input: dataset_points contains NaN coordinates, or both +inf and -inf along one axis. The reference builds its kd-tree over "
+                "NaN bounds for such data and returns rows that depend on the traversal; not supported (non-finite query points and single-signed "
+                "infinities in the dataset are handled as the reference handles them).");
+}
 // After the call's single read-back + stream sync: look at the counters; finish whatever is still unresolved with coarser dataset grids
 // (host-driven, one sync per pass; only far-away / isolated queries ever get here).
 // Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, 3 if the call is to be restarted (rescale_wanted),
@@ -943,6 +929,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     // (one D2H copy + one stream sync for the whole call in the common case)
     int hc_redo[C_N], hc_large[C_N];
     bool redone = false;
+    if (hc[C_LARGE] & 4) return nonfinite_error(j.bad_q != 0);
     if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[finish] role=%d n=%d occ=%.3f may=%d skew=%d large=%d u1=%d u2=%d t1=%d\n", j.role, j.ridx.n, j.occ, (int)j.may_rescale, hc[C_SKEW], hc[C_LARGE], hc[C_U1], hc[C_U2], hc[C_T1]);
     if (hc[C_LARGE]) {
         // Every pass gave up at once because an index was not ready (GridParams::has_large).
@@ -1115,6 +1102,14 @@ template <typename T> static const GridIndex<T>& index_grid(const pcu_hip_index*
 template <> const GridIndex<float>& index_grid<float>(const pcu_hip_index* p) { return p->g32; }
 template <> const GridIndex<double>& index_grid<double>(const pcu_hip_index* p) { return p->g64; }
 
+// Operators that do not run the grid searches (which carry the check, search.h: index_not_ready) look at the flags themselves: one read-back.
+template <typename T>
+static int check_nonfinite(const GridParams<T>* gp, int mask, hipStream_t s) {
+    int nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, reinterpret_cast<const char*>(gp) + offsetof(GridParams<T>, nonfinite), sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return (nf & mask) ? nonfinite_error(false) : 0;
+}
 // k beyond the grid search's capacity (k > 127): the reference's own algorithm for every query -- its kd-tree, rebuilt on the GPU
 // (kd_order.h), and its traversal with a wave-cooperative result set of k slots (k_kd_search_all). Any k > 0 is answered, as
 // the reference does (src/point_cloud_distance.cpp:133-135); slots beyond the dataset size are padded (-1, -1.0) (:90-93).
@@ -1146,6 +1141,7 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
         GridIndex<T> gi;                          // only its exact bounding box is used (root of the kd-tree)
         if (pidx) gi = index_grid<T>(pidx);
         else { if ((rc = index_alloc(ar, gi, nr, 2.0))) break; if ((rc = index_build(gi, dr, 2.0, s))) break; if (st) st->n_grid_builds = 1; }
+        if ((rc = check_nonfinite<T>(gi.gp, kNfNaN | kNfBothInf, s))) break;
         KdBuild<T> b; int* err = nullptr; int levels = 0;
         if ((rc = kd_build_device(c, ar, s, dr, (int)nr, gi.gp, max_leaf > 0 ? max_leaf : 10, b, &err, &levels, nullptr))) break;
         KdSearchArgs<T> a;
@@ -1317,12 +1313,9 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ_x, double occ_y, boo
     return b;
 }
 template <typename T>
-static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, hipStream_t s2, PairState<T>& P, pcu_hip_stats* st) {
-    if (P.two && s2 == s) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
-    else {
-        if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
-        if (P.two && search_enqueue(c, s2, P.yx, st, false)) return -1;
-    }
+static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
+    if (P.two) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
+    else if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
     if (P.fuse) {               // the launch that ends a fused call (reduce.h)
         hipLaunchKernelGGL(k_fuse_tail<T>, dim3(1), dim3(kTailThreads), 0, s, P.tail);
         HIP_TRY(hipGetLastError());
@@ -1345,6 +1338,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = occ_y; P.yx.occ = occ_x;            // a direction's occupancy is its dataset's
     P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
+    P.xy.bad_r = P.xy.bad_q = P.yx.bad_r = P.yx.bad_q = kNfNaN | kNfBothInf | kNfAnyInf;
     job_rescale_setup(c, P.xy, P.allow_rescale, 1); job_rescale_setup(c, P.yx, P.allow_rescale, 0);
     if (aalloc(ar, &P.cb, 1)) return -1;
     P.rb = &P.cb->rb;
@@ -1354,13 +1348,11 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     if (aalloc(ar, &P.tie_hit, 16)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
-    // fork: cloud y is indexed on the aux stream while cloud x is indexed on s
-    // (measured: the passes are throughput-bound, so the overlap only buys ~3 %; off unless PCU_HIP_TWO_STREAMS is set)
-    hipStream_t s2 = two_sided && getenv("PCU_HIP_TWO_STREAMS") ? c->aux_stream : s;
+    // (indexing cloud y on a second stream beside cloud x was measured in round 1: ~3 %, less than sharing every launch; removed)
     // fused attempt: only when every direction takes the k = 1 lane-per-query kernel on one stream
     static const bool no_fuse = getenv("PCU_HIP_NO_FUSE") != nullptr;
     P.fuse = FUSE_NONE;
-    if (fuse_mode != FUSE_NONE && !no_fuse && s2 == s && lane_k1_job(P.xy) && (!two_sided || lane_k1_job(P.yx))) {
+    if (fuse_mode != FUSE_NONE && !no_fuse && lane_k1_job(P.xy) && (!two_sided || lane_k1_job(P.yx))) {
         P.fuse = fuse_mode;
         FuseTail<T>& t = P.tail; memset(&t, 0, sizeof t);
         t.mode = fuse_mode; t.njobs = two_sided ? 2 : 1; t.nwaves = kWaveBlocks * (kBlock / 64);
@@ -1378,19 +1370,12 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
         t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;
     }
     tm.mark(0);
-    if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[0], s)); HIP_TRY(hipStreamWaitEvent(s2, c->jev[0], 0)); }
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (s2 == s) { if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1; }
-    else if (index_build(ix, P.dx, occ_x, s, !c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4)) || index_build(iy, P.dy, occ_y, s2, !c->eager_large)) return -1;
-    if (s2 != s) {      // both searches need both indices
-        HIP_TRY(hipEventRecord(c->jev[1], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
-        HIP_TRY(hipEventRecord(c->jev[2], s));  HIP_TRY(hipStreamWaitEvent(s2, c->jev[2], 0));
-    }
+    if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1;
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
-    if (pair_search_enqueue(c, s, s2, P, st)) return -1;
-    if (s2 != s) { HIP_TRY(hipEventRecord(c->jev[3], s2)); HIP_TRY(hipStreamWaitEvent(s, c->jev[3], 0)); }   // join
+    if (pair_search_enqueue(c, s, P, st)) return -1;
     tm.mark(2);
     return 0;
 }
@@ -1462,7 +1447,7 @@ static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, p
     P.fuse = FUSE_NONE; P.xy.fuse = P.yx.fuse = FUSE_NONE;
     HIP_TRY(hipMemsetAsync(P.cb, 0, sizeof(CallBlock), s));
     if (st) { st->n_passes = 0; }
-    return pair_search_enqueue(c, s, s, P, st);
+    return pair_search_enqueue(c, s, P, st);
 }
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, 3 if the call is to be restarted, <0 on error.
 template <typename T>
@@ -1538,6 +1523,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
             memcpy(&host, c->h_pinned, sizeof host);
+            if ((host.counters[0][C_LARGE] | host.counters[1][C_LARGE]) & 4) { rc = nonfinite_error(true); break; }
             if (fused_ok(P, host, tie_matters)) {
                 for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
@@ -1652,6 +1638,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
             memcpy(&host, c->h_pinned, sizeof host);
+            if ((host.counters[0][C_LARGE] | host.counters[1][C_LARGE]) & 4) { rc = nonfinite_error(true); break; }
             if (fused_ok(P, host, false)) {
                 for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
@@ -1842,64 +1829,39 @@ static int batch_run(pcu_hip_ctx* c, int n_pairs, unsigned flags, void* stream, 
     if (n_pairs < 0) return fail(PCU_HIP_ERR_INVALID, "negative number of pairs");
     if (st) memset(st, 0, sizeof *st);
     if (n_pairs == 0) return 0;
-    // Optional: several host threads, each enqueueing into lanes of its own (PCU_HIP_BATCH_THREADS, default 1). Measured on 32
-    // pairs of 262k points: what counts is the number of pairs in flight -- 3 is the optimum whether one thread drives them
-    // (55.9 us per pair) or three do (58.8); 4 and more are slower with any thread count (64-78 us).
-    static const int n_threads_env = [] { const char* e = getenv("PCU_HIP_BATCH_THREADS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
-    const int n_threads = std::max(1, std::min(n_threads_env, n_pairs / 2));
-    const int per_thread = std::max(1, std::min(c->n_lanes_wanted, 16 / n_threads));
-    const int saved_want = c->n_lanes_wanted;
-    c->n_lanes_wanted = per_thread * n_threads;
-    const int L_all = batch_lanes(c, n_pairs, stream, flags);
-    c->n_lanes_wanted = saved_want;
-    if (L_all < 0) return PCU_HIP_ERR_RUNTIME;
+    // One host thread drives all lanes. (Several host threads, each with lanes of its own, were measured in round 2 on 32 pairs of
+    // 262k points: what counts is the number of pairs in flight -- 3 is the optimum either way, 55.9 vs 58.8 us per pair; removed.)
+    const int L = batch_lanes(c, n_pairs, stream, flags);
+    if (L < 0) return PCU_HIP_ERR_RUNTIME;
     const unsigned lflags = flags & ~(unsigned)(PCU_HIP_STREAM_GIVEN | PCU_HIP_TIME_PHASES | PCU_HIP_TIME_KERNELS);
-    std::mutex mu;
-    int rc_all = 0; std::string err_all;
-    auto work = [&](int t) {
-        DeviceGuard dg(c->device);
-        // this thread's lanes and pairs: lanes [l0, l1), pairs t, t + n_threads, ...
-        const int l0 = (int)((long long)L_all * t / n_threads), l1 = (int)((long long)L_all * (t + 1) / n_threads);
-        const int L = l1 - l0;
-        if (L <= 0) return;
-        std::vector<PendingPair<T>> pend((size_t)L);
-        std::vector<pcu_hip_stats> lst((size_t)L);
-        std::vector<int> cur((size_t)L, -1);
-        int rc = 0; std::string err;
-        int k = 0;
-        const int mine = (n_pairs - t + n_threads - 1) / n_threads;
-        for (int it = 0; it < mine + L; ++it) {
-            const int lane = it % L;
-            if (cur[lane] >= 0) {
-                int r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
-                for (int restarts = 1; r == PCU_RETRY; ++restarts) {         // occupancy rescale: the lane's context has a new scale
-                    pend[lane] = PendingPair<T>(); pend[lane].restarts = restarts;
-                    pcu_hip_stats again;
-                    r = begin(c->lanes[l0 + lane], pend[lane], cur[lane], lflags, &again);
-                    if (!r) r = end(c->lanes[l0 + lane], pend[lane], cur[lane]);
-                }
-                if (r && !rc) { rc = r; err = g_err; }
-                { std::lock_guard<std::mutex> g(mu); stats_add(st, lst[lane]); }
-                cur[lane] = -1;
+    std::vector<PendingPair<T>> pend((size_t)L);
+    std::vector<pcu_hip_stats> lst((size_t)L);
+    std::vector<int> cur((size_t)L, -1);
+    int rc = 0; std::string err;
+    int k = 0;
+    for (int it = 0; it < n_pairs + L; ++it) {
+        const int lane = it % L;
+        if (cur[lane] >= 0) {
+            int r = end(c->lanes[lane], pend[lane], cur[lane]);
+            for (int restarts = 1; r == PCU_RETRY; ++restarts) {         // occupancy rescale: the lane's context has a new scale
+                pend[lane] = PendingPair<T>(); pend[lane].restarts = restarts;
+                pcu_hip_stats again;
+                r = begin(c->lanes[lane], pend[lane], cur[lane], lflags, &again);
+                if (!r) r = end(c->lanes[lane], pend[lane], cur[lane]);
             }
-            if (k < mine && !rc) {
-                const int p = t + k * n_threads; ++k;
-                pend[lane] = PendingPair<T>();
-                const int r = begin(c->lanes[l0 + lane], pend[lane], p, lflags, &lst[lane]);
-                if (r) { rc = r; err = g_err; } else cur[lane] = p;
-            }
+            if (r && !rc) { rc = r; err = g_err; }
+            stats_add(st, lst[lane]);
+            cur[lane] = -1;
         }
-        if (rc) { std::lock_guard<std::mutex> g(mu); if (!rc_all) { rc_all = rc; err_all = err; } }
-    };
-    if (n_threads == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        if (k < n_pairs && !rc) {
+            const int p = k++;
+            pend[lane] = PendingPair<T>();
+            const int r = begin(c->lanes[lane], pend[lane], p, lflags, &lst[lane]);
+            if (r) { rc = r; err = g_err; } else cur[lane] = p;
+        }
     }
-    if (rc_all) g_err = err_all;
-    return rc_all;
+    if (rc) g_err = err;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ persistent index
@@ -1942,7 +1904,7 @@ static int index_create_impl(pcu_hip_ctx* c, const T* dataset, int64_t nr, int k
             rc = fail(PCU_HIP_ERR_RUNTIME, "internal: index block too small"); break;
         }
         if ((rc = index_build<T>(g, static_cast<const T*>(p->pts), p->occ, s))) break;
-        if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(PCU_HIP_ERR_RUNTIME, "index build failed"); break; }
+        if ((rc = check_nonfinite<T>(g.gp, kNfNaN | kNfBothInf, s))) break;
     } while (0);
     if (rc) { index_free(p); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     *out = p;
@@ -1997,7 +1959,6 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     DeviceGuard dg(device);
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
-    if (const char* e = getenv("PCU_HIP_OCC_SCALE")) { double a = 1, b = 1; if (sscanf(e, "%lf,%lf", &a, &b) == 2) { c->occ_scale[0] = a; c->occ_scale[1] = b; } }   // (debugging: start from given scales)
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

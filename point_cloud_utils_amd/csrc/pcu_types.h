@@ -56,6 +56,7 @@ struct GridParams {
                               // cloud); points beyond the grid border exist but are not in it, so border faces count
     int has_large;            // 1: the bucketed build met over-full buckets whose records are not placed yet (k_bucket_large is
                               // launched only on demand: searches see this flag, give up and tell the host, pcu_hip.hip C_LARGE)
+    int nonfinite;            // kNf* flags (grid.h): non-finite coordinates met by the bbox pass
     unsigned long long sumsq; // sum over cells of count^2 (balance metric: sumsq / n = mean number of cell mates)
 };
 

@@ -72,7 +72,15 @@ struct SearchArgs {
     unsigned long long* f_limbs; double* f_special; T* f_wave_v; long long* f_wave_k;
     int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
                                     // slots instead of overwriting them
+    int bad_r, bad_q;               // GridParams::nonfinite flags (grid.h: kNf*) of the dataset / of the query cloud that this operator rejects:
+                                    // the passes give up at once and raise bit 2 of the large-bucket flag word (-> ValueError on the host)
 };
+// The "index not usable" word of a pass: over-full buckets (1), one-pass overflow (2), rejected non-finite input (4).
+template <typename T>
+__device__ __forceinline__ int index_not_ready(const SearchArgs<T>& a, const GridParams<T>& g) {
+    const GridParams<T>& qg = *a.qgp;
+    return g.has_large | qg.has_large | (((g.nonfinite & a.bad_r) | (qg.nonfinite & a.bad_q)) ? 4 : 0);
+}
 
 constexpr int kLargeFlag = 3;      // counters[C_LARGE] relative to counters[C_SKEW] (pcu_hip.hip)
 
@@ -199,19 +207,6 @@ __device__ __forceinline__ float kill_if(float d, bool dead) { return __uint_as_
 __device__ __forceinline__ double kill_if(double d, bool dead) {
     return __longlong_as_double(__double_as_longlong(d) | (dead ? 0x7ff0000000000000ll : 0ll));
 }
-template <typename T, int K>
-__device__ __forceinline__ void offer4(const Pt4<T>& q, const Pt4<T>& c0, const Pt4<T>& c1, const Pt4<T>& c2, const Pt4<T>& c3,
-                                       unsigned p, unsigned e, T (&bd)[K], int (&bi)[K], bool& tie) {
-    const T d0 = dist2(q, c0);
-    const T d1 = kill_if(dist2(q, c1), p + 1 >= e);
-    const T d2 = kill_if(dist2(q, c2), p + 2 >= e);
-    const T d3 = kill_if(dist2(q, c3), p + 3 >= e);
-    offer<T, K>(d0, (int)c0.idx, bd, bi, tie);
-    offer<T, K>(d1, (int)c1.idx, bd, bi, tie);
-    offer<T, K>(d2, (int)c2.idx, bd, bi, tie);
-    offer<T, K>(d3, (int)c3.idx, bd, bi, tie);
-}
-
 // Certification, output and list appends of one lane (shared by the gather and the LDS-tile main passes).
 // `valid` is false for padding lanes of a partial wave (they only take part in the wave-wide list appends).
 template <typename T, int K>
@@ -268,8 +263,8 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
+    if (const int hl = index_not_ready(a, g)) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
-    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     // A closed sub-box level (dense part of an unbalanced cloud) can never certify a query outside its box [org, org + G h) --
     // face_lower_bound is then at most the query's distance to the level's points, which no candidate beats -- so such a query goes to
@@ -424,8 +419,8 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
     const GridParams<T>& g = *a.gp;
+    if (const int hl = index_not_ready(a, g)) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
-    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -589,228 +584,9 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     f_v = a.squared ? best : sqrt(best);
     f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
 }
-// -------------------------------------------------------------------------------------------------------
-// Balanced variant of the k = 1 main pass (float). Measured on MI355X (profiles/ubench/ta_rate.hip): a per-lane gather
-// instruction occupies the CU's texture-address path for ~17-21 cycles whatever its width (8/12/16 B) and HOWEVER FEW
-// LANES ARE ACTIVE (2 of 64: 21 cycles); k_search1_flat's 71 vector-memory instructions per wave x ~19 cycles are its
-// run time (TA busy 80 %), and its per-lane run loop executes max-over-lanes trips at ~40 % active lanes. Here the lanes
-// only scan their own centre row; the surviving cut runs of the other eight rows are cut into groups of 4 records and
-// pooled in a per-wave LDS queue, which the 64 lanes then consume TOGETHER, 64 groups per trip, whoever's they are:
-//   item   = (first record of the group) << 6 | owner lane                               [4 bytes]
-//   worker : owner's query from LDS, 4 records, minimum + which record, then
-//            old = ds_min_rtn_u64(key[owner], d2 bits << 32 | record offset)             [d2 >= 0: its bits order like the value]
-//            equal d2 from ANOTHER record (old, or twice inside the group) -> ds_min_u32(tie[owner], d2 bits)
-//   owner  : best = key >> 32, record = key & 0xffffffff, possible tie iff tie == best bits (flags are only raised at a
-//            value that was the running minimum, so the smallest flagged value equals the final minimum iff that minimum
-//            was met in two different records). A record seen twice (groups run past their run's end) has the same
-//            offset both times and raises nothing; no masking, no re-identification of the winner afterwards.
-// LDS is in order per wave, so the queue, the keys and the flags need no barrier beyond keeping the compiler from
-// reordering. Lanes beyond the end of the query list stay as workers. When a wave's groups exceed the queue the lanes past
-// the limit hand their queries to the wave-per-query pass (like lane_max_cand). Requires n_ref < 2^26.
-#ifndef PCU_BAL_QUEUE
-#define PCU_BAL_QUEUE 768
-#endif
-constexpr int kBalQueue = PCU_BAL_QUEUE;          // groups per wave (mean on uniform clouds: 260)
-template <bool EARLY, int FUSE>
-__device__ __forceinline__ void search1_bal_body(const SearchArgs<float>& a, const int nq_arg, const int bid, const int nblk, bool& f_ok, float& f_v, long long& f_key) {
-    typedef float T;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ f32x4 s_q[kBlock];
-    __shared__ unsigned long long s_key[kBlock];
-    __shared__ unsigned s_tie[kBlock];
-    __shared__ unsigned s_item[kBlock / 64][kBalQueue];
-    const int per = nblk >> 3;
-    const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search
-    const int nq = a.qcount_dev ? *a.qcount_dev : nq_arg;
-    if (vb * kBlock >= nq) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wb = tid & ~63;
-    const bool alive = vb * kBlock + tid < nq;
-    const int t = alive ? vb * kBlock + tid : nq - 1;          // lanes past the end mirror the last query and only work for others
-    const int qpos = a.qlist ? a.qlist[t] : t;
-    const Pt4<T> q = a.qsorted[qpos];
-    const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
-    if (const int hl = g.has_large | a.qgp->has_large) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
-    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
-    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
-    const int len = x1 - x0 + 1;
-    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
-    const char* const base = reinterpret_cast<const char*>(a.ref);
-    const unsigned cand_cap = a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u;
-    T best = Limits<T>::max_v;
-    unsigned brec = 0xffffffffu;
-    bool tie = false;
-    auto row_table = [&](int j, bool& ok, bool& odd) {
-        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
-        ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
-        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
-        odd = row & 1;
-        return *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
-    };
-    bool okj[9], oddj[9];
-    CellStart4 tb[9];
-    tb[0] = row_table(0, okj[0], oddj[0]);
-    if (EARLY) {
-#pragma unroll
-        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
-    }
-    // ---- centre row: whole run, by its own lane (gives the minimum the other rows are cut against)
-    const unsigned cnt0 = (len == 3 ? tb[0].v[3] : (len == 2 ? tb[0].v[2] : tb[0].v[1])) - tb[0].v[0];
-    bool defer = cnt0 > cand_cap;
-    // Three groups per trip, all requested together (the kernel is a chain of memory round trips: one for 98 % of the waves
-    // instead of one per group; a wave ran 3.1 single-group trips on uniform clouds, so this issues no more loads). A lane
-    // whose run has ended fetches the +inf sentinel records, which change nothing.
-    {
-        const unsigned o0 = tb[0].v[0] * kRec;
-        const unsigned o1 = defer ? o0 : o0 + cnt0 * kRec;
-        const unsigned sent = a.n_ref * kRec;
-        auto eval = [&](const Pt4<T>& c0, const Pt4<T>& c1, const Pt4<T>& c2, const Pt4<T>& c3, const unsigned off) {
-            const T d0 = dist2_k1(q, c0), d1 = dist2_k1(q, c1), d2 = dist2_k1(q, c2), d3 = dist2_k1(q, c3);
-            const T m = min4(d0, d1, d2, d3);
-            const bool e0 = d0 == m, e1 = d1 == m, e2 = d2 == m, e3 = d3 == m;
-            const bool multi = (int)e0 + (int)e1 + (int)e2 + (int)e3 > 1;
-            const unsigned mrec = off + (e0 ? 0u : (e1 ? kRec : (e2 ? 2u * kRec : 3u * kRec)));
-            const bool lt = m < best, eq = m == best;
-            tie = lt ? multi : (tie || (eq && (multi || mrec != brec)));
-            brec = lt ? mrec : brec;
-            best = lt ? m : best;
-        };
-        for (unsigned off = o0; __any(off < o1); off += 12u * kRec) {
-            const unsigned f0 = off < o1 ? off : sent, f1 = off + 4u * kRec < o1 ? off + 4u * kRec : sent, f2 = off + 8u * kRec < o1 ? off + 8u * kRec : sent;
-            // (the loads are straight-line code: loads issued under a branch, even a wave-uniform one, are waited for at its end)
-            const Pt4<T>* p0 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f0);
-            const Pt4<T>* p1 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f1);
-            const Pt4<T>* p2 = reinterpret_cast<const Pt4<T>*>(base + (size_t)f2);
-            const Pt4<T> c0 = p0[0], c1 = p0[1], c2 = p0[2], c3 = p0[3], c4 = p1[0], c5 = p1[1], c6 = p1[2], c7 = p1[3], c8 = p2[0], c9 = p2[1], c10 = p2[2], c11 = p2[3];
-            eval(c0, c1, c2, c3, f0);
-            eval(c4, c5, c6, c7, f1);
-            eval(c8, c9, c10, c11, f2);
-        }
-    }
-    if (!EARLY) {
-#pragma unroll
-        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
-    }
-    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
-    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
-    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
-    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
-    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;
-    T my2[3], mz2[3];
-    {
-        T m;
-        my2[0] = (T)0; mz2[0] = (T)0;
-        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
-        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
-        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
-        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
-    }
-    unsigned total = cnt0;
-#pragma unroll
-    for (int j = 1; j < 9; ++j) total += okj[j] ? (len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1])) - tb[j].v[0] : 0u;
-    defer = defer || total > cand_cap;
-    // ---- the other rows: cut runs that survive the centre row's minimum, as groups of 4 records
-    unsigned rrec[8], rgrp[8];          // first record / number of groups of row j+1's cut run
-    unsigned ng = 0;
-#pragma unroll
-    for (int j = 1; j < 9; ++j) {
-        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
-        const T rlb = ry + rz;
-        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
-        const bool cut_first = oddj[j] ? cut_hi : cut_lo, cut_last = oddj[j] ? cut_lo : cut_hi;
-        const unsigned s_run = cut_first ? tb[j].v[1] : tb[j].v[0];
-        const unsigned e_full = len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1]);
-        const unsigned e_cut = len == 3 ? tb[j].v[2] : (len == 2 ? tb[j].v[1] : tb[j].v[0]);
-        const unsigned e_run = cut_last ? e_cut : e_full;
-        const bool on = alive && okj[j] && !defer && !(best < rlb) && e_run > s_run;
-        rrec[j - 1] = s_run;
-        rgrp[j - 1] = on ? (e_run - s_run + 3u) >> 2 : 0u;
-        ng += rgrp[j - 1];
-    }
-    // the lane's slice of the wave's queue; lanes whose slice would end beyond the queue (a prefix property: all lanes from the
-    // first such one on) hand their queries to the wave-per-query pass
-    unsigned inc = ng;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-    const bool fits = inc <= (unsigned)kBalQueue;
-    const unsigned long long fit_mask = __ballot(fits);
-    if (!fits) {
-        defer = true;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rgrp[j] = 0;
-    }
-    const int n_items = fit_mask ? (int)__shfl(inc, 63 - __clzll((long long)fit_mask), 64) : 0;
-    s_q[tid] = f32x4{q.x, q.y, q.z, 0.f};
-    s_key[tid] = ((unsigned long long)__float_as_uint(best) << 32) | brec;
-    s_tie[tid] = tie ? __float_as_uint(best) : 0xffffffffu;
-    unsigned* const items = s_item[wv];
-    {
-        unsigned pos = inc - ng;          // (deferred lanes write nothing)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            for (unsigned gi = 0; __any(gi < rgrp[j]); ++gi)
-                if (gi < rgrp[j]) items[pos + gi] = ((rrec[j] + 4u * gi) << 6) | (unsigned)lane;
-            pos += rgrp[j];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- the queue, 64 groups per trip; the next trip's item and records are requested before this trip's are evaluated
-    if (n_items > 0) {
-        const int last = n_items - 1;
-#define PCU_BAL_EVAL(IT, C0, C1, C2, C3)                                                                              \
-        {                                                                                                             \
-            const unsigned own_ = (unsigned)wb + ((IT) & 63u), off_ = ((IT) & 0xffffffc0u) >> 2;                      \
-            const f32x4 oq_ = s_q[own_];                                                                              \
-            Pt4<T> Q_; Q_.x = oq_.x; Q_.y = oq_.y; Q_.z = oq_.z;                                                      \
-            const T d0_ = dist2_k1(Q_, C0), d1_ = dist2_k1(Q_, C1), d2_ = dist2_k1(Q_, C2), d3_ = dist2_k1(Q_, C3);   \
-            const T m_ = min4(d0_, d1_, d2_, d3_);                                                                    \
-            const bool e0_ = d0_ == m_, e1_ = d1_ == m_, e2_ = d2_ == m_, e3_ = d3_ == m_;                            \
-            const bool multi_ = (int)e0_ + (int)e1_ + (int)e2_ + (int)e3_ > 1;                                        \
-            const unsigned mrec_ = off_ + (e0_ ? 0u : (e1_ ? kRec : (e2_ ? 2u * kRec : 3u * kRec)));                  \
-            const unsigned mb_ = __float_as_uint(m_);                                                                 \
-            const unsigned long long old_ = atomicMin(&s_key[own_], ((unsigned long long)mb_ << 32) | mrec_);         \
-            if (multi_ || ((unsigned)(old_ >> 32) == mb_ && (unsigned)old_ != mrec_)) atomicMin(&s_tie[own_], mb_);   \
-        }
-        for (int i0 = 0; i0 < n_items; i0 += 128) {           // two trips' items and records requested together, branch-free
-            const unsigned ia = items[min(i0 + lane, last)], ib = items[min(i0 + 64 + lane, last)];        // (past the end: the last item again -- no effect)
-            const Pt4<T>* pa = reinterpret_cast<const Pt4<T>*>(base + (size_t)((ia & 0xffffffc0u) >> 2));
-            const Pt4<T>* pb = reinterpret_cast<const Pt4<T>*>(base + (size_t)((ib & 0xffffffc0u) >> 2));
-            const Pt4<T> a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
-            PCU_BAL_EVAL(ia, a0, a1, a2, a3)
-            PCU_BAL_EVAL(ib, b0, b1, b2, b3)
-        }
-#undef PCU_BAL_EVAL
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (!alive) return;
-    {
-        const unsigned long long key = s_key[tid];
-        best = __uint_as_float((unsigned)(key >> 32));
-        brec = (unsigned)key;
-        tie = s_tie[tid] == (unsigned)(key >> 32);
-    }
-    T bd[1] = {best};
-    int bi[1] = {0x7fffffff};
-    if (FUSE != FUSE_SUM && brec != 0xffffffffu) bi[0] = reinterpret_cast<const Pt4<T>*>(base + (size_t)brec)->idx;      // (a sum needs no index: one round trip less)
-    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
-    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer); return; }
-    if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
-        wave_append(true, qpos, a.ties, a.n_ties);
-        return;
-    }
-    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
-    const bool certified = best < lb;
-    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
-    f_ok = certified;
-    f_v = a.squared ? best : sqrt(best);
-    f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
-}
-
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
 template <typename T> struct SearchArgs2 { SearchArgs<T> a[2]; };
-template <typename T, bool EARLY, int MINW, int FUSE, bool BAL = false>
+template <typename T, bool EARLY, int MINW, int FUSE>
 __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2<T> p, int nb0) {
     // (the side's arguments are read through an index into the kernel-argument segment; selecting between two by-value
     // structs by reference makes the compiler copy the chosen one to scratch)
@@ -820,8 +596,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
     // (nq is picked by a scalar select: read through p.a[side] the compiler parks both sides' values in SCRATCH to index them --
     // 8 bytes of private memory written per lane, 16 MB of HBM writes per 1M-vs-1M launch, profiles/r02a_pmc.txt)
     const int nq_side = side ? p.a[1].nq : p.a[0].nq;
-    if constexpr (BAL && sizeof(T) == 4) search1_bal_body<EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
-    else search1_flat_body<T, EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
+    search1_flat_body<T, EARLY, FUSE>(p.a[side], nq_side, bid, side ? (int)gridDim.x - nb0 : nb0, ok, v, key);
     if (FUSE == FUSE_SUM) {                     // one fp64 partial per block; lanes in a fixed order: reproducible
         const double r = block_sum(ok ? (double)v : 0.0);
         if (threadIdx.x == 0) p.a[side].f_sum[bid] = r;
@@ -830,135 +605,6 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
         block_argmax(bv, bk);
         if (threadIdx.x == 0) { p.a[side].f_max_v[bid] = bv; p.a[side].f_max_k[bid] = bk; }
     }
-}
-
-// -------------------------------------------------------------------------------------------------------
-// Main pass, LDS-tiled (the default): ONE WAVE = 64 consecutive queries of the cell-ordered query cloud, i.e. a
-// compact snake of query cells. The wave takes the bounding box of its lanes' dataset cells (+1 cell), and for
-// that box
-//   1. loads the box's slice of `cell_start` (one coalesced load per (y,z) row) into LDS,
-//   2. copies the box's dataset records into LDS with coalesced 16-byte loads (a row of the box is one contiguous
-//      run of `sorted`), in groups of rows that fit the wave's LDS slice,
-//   3. lets every lane scan ITS OWN 27 cells out of LDS (ds_read_b128 per candidate, query in registers).
-// Every dataset record the wave needs is thus fetched from L2/HBM exactly once per wave by a wide coalesced load
-// instead of ~3 times by scattered 16-byte per-lane gathers (the gather kernel k_search is TA/L1-throughput
-// bound). Waves whose box does not fit the tables (very uneven data) fall back to the gather code, rows that do
-// not fit the record buffer are gathered from global memory by the lanes; results are identical either way.
-constexpr int kTileNX = 48;        // max cells per box row  (+1 prefix entry)
-constexpr int kTileNR = 16;        // max (y,z) rows per box
-template <typename T> struct TileCap { static constexpr int refs = sizeof(T) == 4 ? 640 : 320; };   // records per LDS slice (10 KB)
-
-template <typename T, int K>
-__device__ __forceinline__ void scan_range(const Pt4<T>* __restrict__ base, unsigned s, unsigned e, const Pt4<T>& q,
-                                           T (&bd)[K], int (&bi)[K], bool& tie) {
-    for (unsigned p = s; p < e; p += 4) {
-        const unsigned last = e - 1;
-        const Pt4<T> c0 = base[p], c1 = base[min(p + 1, last)], c2 = base[min(p + 2, last)], c3 = base[min(p + 3, last)];
-        offer4<T, K>(q, c0, c1, c2, c3, p, e, bd, bi, tie);
-    }
-}
-
-template <typename T, int K>
-__global__ __launch_bounds__(64) void k_search_tile(const SearchArgs<T> a) {
-    __shared__ __attribute__((aligned(16))) Pt4<T> s_ref[TileCap<T>::refs];
-    __shared__ unsigned s_cs[kTileNR][kTileNX + 1];
-    __shared__ unsigned s_rowbase[kTileNR + 1];
-    // XCD-aware block order (see k_search): each XCD works on one contiguous eighth of the cell-ordered queries
-    const int per = (int)(gridDim.x >> 3);
-    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    const int lane = threadIdx.x;
-    const int nq = a.nq;
-    const int t0 = vb * 64;
-    if (t0 >= nq) return;
-    const bool valid = t0 + lane < nq;
-    const int qpos = valid ? t0 + lane : nq - 1;            // padding lanes mirror the last query (no effect on the box)
-    const Pt4<T> q = a.qsorted[qpos];
-    const GridParams<T>& g = *a.gp;
-    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t0 == 0 && lane == 0) *a.skew_flag = 1; return; }
-    if (const int hl = g.has_large | a.qgp->has_large) { if (t0 == 0 && lane == 0) a.skew_flag[kLargeFlag] = hl; return; }
-    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
-    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
-    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
-    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-    // wave box
-    int X0 = x0, X1 = x1, Y0 = y0, Y1 = y1, Z0 = z0, Z1 = z1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        X0 = min(X0, __shfl_xor(X0, o, 64)); X1 = max(X1, __shfl_xor(X1, o, 64));
-        Y0 = min(Y0, __shfl_xor(Y0, o, 64)); Y1 = max(Y1, __shfl_xor(Y1, o, 64));
-        Z0 = min(Z0, __shfl_xor(Z0, o, 64)); Z1 = max(Z1, __shfl_xor(Z1, o, 64));
-    }
-    const int nx = X1 - X0 + 1, ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
-
-    T bd[K];
-    int bi[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
-    bool tie = false;
-
-    if (nx > kTileNX || nrows > kTileNR) {
-        // box too large for the tables: plain per-lane gather from global memory
-        for (int cz = z0; cz <= z1; ++cz)
-            for (int cy = y0; cy <= y1; ++cy) {
-                const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
-                scan_range<T, K>(a.ref, a.cell_start[lo], a.cell_start[lo + (x1 - x0 + 1)], q, bd, bi, tie);
-            }
-    } else {
-        // 1. the box's slice of cell_start: row r = (cz - Z0) * ny + (cy - Y0), entries for cells X0 .. X1+1
-        for (int r = 0; r < nrows; ++r) {
-            const int lo = row_run_lo(Gx, grid_row(Gy, Y0 + r % ny, Z0 + r / ny), X0, X1);
-            if (lane <= nx) s_cs[r][lane] = a.cell_start[lo + lane];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 2./3. groups of consecutive rows whose records fit the LDS slice
-        int r0 = 0;
-        while (r0 < nrows) {
-            // greedy group [r0, r1): lane r holds the size of row r0 + r, inclusive scan, count rows that fit
-            const int rr = r0 + lane;
-            const unsigned cnt = (rr < nrows) ? s_cs[rr][nx] - s_cs[rr][0] : 0u;
-            unsigned inc = cnt;
-#pragma unroll
-            for (int o = 1; o < kTileNR; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-            const unsigned long long fits = __ballot(rr < nrows && inc <= (unsigned)TileCap<T>::refs);
-            int ng = fits ? __ffsll((long long)~fits) - 1 : 0;        // leading run of rows that fit (rows are in lane order)
-            if (ng > nrows - r0) ng = nrows - r0;
-            if (ng == 0) {
-                // one row alone exceeds the slice: its cells are gathered from global memory by the lanes that need it
-                const int cy = Y0 + r0 % ny, cz = Z0 + r0 / ny;
-                if (cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1) {
-                    const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
-                    scan_range<T, K>(a.ref, a.cell_start[lo], a.cell_start[lo + (x1 - x0 + 1)], q, bd, bi, tie);
-                }
-                r0 += 1;
-                continue;
-            }
-            if (lane < ng) s_rowbase[lane] = inc - cnt;
-            const unsigned total = __shfl(inc, ng - 1, 64);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // coalesced copy: flat index -> (row, offset) by a short search in the row bases
-            for (unsigned idx = lane; idx < total; idx += 64) {
-                int lo = 0, hi = ng;
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= idx) lo = mid; else hi = mid; }
-                s_ref[idx] = a.ref[s_cs[r0 + lo][0] + (idx - s_rowbase[lo])];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // each lane: its rows inside this group
-            for (int cz = z0; cz <= z1; ++cz)
-                for (int cy = y0; cy <= y1; ++cy) {
-                    const int r = (cz - Z0) * ny + (cy - Y0);
-                    if (r < r0 || r >= r0 + ng) continue;
-                    const unsigned b0 = s_cs[r][0];
-                    const bool odd = grid_row(Gy, cy, cz) & 1;       // odd rows run in -x: the table is mirrored
-                    const int i0 = odd ? X1 - x1 : x0 - X0, i1 = odd ? X1 - x0 + 1 : x1 + 1 - X0;
-                    const unsigned s = s_rowbase[r - r0] + (s_cs[r][i0] - b0), e = s_rowbase[r - r0] + (s_cs[r][i1] - b0);
-                    scan_range<T, K>(s_ref, s, e, q, bd, bi, tie);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            r0 += ng;
-        }
-    }
-    finish_lane<T, K>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, valid);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -992,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     const int* const c10 = a1.qcount_dev ? a1.qcount_dev : a1.skew_flag; const int* const c11 = a1.qlist2 ? a1.qcount2_dev : a1.skew_flag;
     const int v00 = *c00, v01 = *c01, v10 = *c10, v11 = *c11;
     const unsigned long long ss0 = a0.gp->sumsq, ss1 = a1.gp->sumsq;
-    const int hl0 = a0.gp->has_large | a0.qgp->has_large, hl1 = a1.gp->has_large | a1.qgp->has_large;
+    const int hl0 = index_not_ready(a0, *a0.gp), hl1 = index_not_ready(a1, *a1.gp);
     int total0 = (a0.qcount_dev ? v00 : a0.nq) + (a0.qlist2 ? v01 : 0);
     int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
     if (a0.skew_limit > 0.f && ((float)ss0 > a0.skew_limit || (float)ss0 < a0.skew_lo)) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }

@@ -24,8 +24,11 @@ namespace pcu {
 // one thread per output element; a block covers 64 consecutive j of 4 consecutive i (coalesced stores, the a rows and b rows it
 // reads are shared through L1)
 template <typename T>
-__global__ __launch_bounds__(256) void k_pairwise(const T* __restrict__ a, const T* __restrict__ b, int m, int n, int d, int pcode, double p, T* __restrict__ out) {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6), bt = blockIdx.z;
+__global__ __launch_bounds__(256) void k_pairwise(const T* __restrict__ a, const T* __restrict__ b, int m, int n, int d, int pcode, double p, T* __restrict__ out, int col_blocks) {
+    // (rows x column blocks are folded into gridDim.x -- 2^31-1 blocks -- because gridDim.y / .z end at 65535: 100k points against 100
+    // centroids is a legitimate call)
+    const int bx = (int)(blockIdx.x % (unsigned)col_blocks), by = (int)(blockIdx.x / (unsigned)col_blocks);
+    const int j = bx * 64 + (threadIdx.x & 63), i = by * 4 + (threadIdx.x >> 6), bt = blockIdx.y;
     if (i >= m || j >= n) return;
     const T* ai = a + ((size_t)bt * m + i) * d; const T* bj = b + ((size_t)bt * n + j) * d;
     T acc = pcode == P_NINF ? (T)INFINITY : (T)0;
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(1024) void k_sink_cols(const SinkArgs<T> s, T* __re
     if (j < s.n)
         for (int i = i0 + r; i < i1; i += 32) {
             const T x = (-Mb[(size_t)i * s.n + j] + u[i]) / s.eps;
-            if (x > mx) { acc = acc * exp(mx - x) + (T)1; mx = x; } else acc += exp(x - mx);
+            // (x = -inf -- a forbidden assignment M = +inf, or u = -inf from a zero weight -- adds exp(-inf) = 0, as in the reference's
+            // max-subtracted sum; exp(x - mx) would be exp(NaN) while the running maximum is still -inf)
+            if (x > mx) { acc = acc * exp(mx - x) + (T)1; mx = x; } else if (x != -(T)INFINITY) acc += exp(x - mx);
         }
     s_mx[r][c] = mx; s_sum[r][c] = acc;
     __syncthreads();
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void k_sink_iter(const SinkArgs<T> s, T* __res
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const T x = (-mv[k] + un) / s.eps;
-            if (x > cmx[k]) { cacc[k] = cacc[k] * exp(cmx[k] - x) + (T)1; cmx[k] = x; } else cacc[k] += exp(x - cmx[k]);
+            if (x > cmx[k]) { cacc[k] = cacc[k] * exp(cmx[k] - x) + (T)1; cmx[k] = x; } else if (x != -(T)INFINITY) cacc[k] += exp(x - cmx[k]);     // (see k_sink_cols)
             mv[k] = nx[k];
         }
     }
@@ -251,8 +256,9 @@ __global__ __launch_bounds__(1024) void k_sink_check(const SinkArgs<T> s, T stop
 }
 // P = exp((-M + u_i + v_j) / eps) (:125-127)
 template <typename T>
-__global__ __launch_bounds__(256) void k_sink_plan(const SinkArgs<T> s, T* __restrict__ P) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, bt = blockIdx.z;
+__global__ __launch_bounds__(256) void k_sink_plan(const SinkArgs<T> s, T* __restrict__ P, int col_blocks) {
+    const int bx = (int)(blockIdx.x % (unsigned)col_blocks), i = (int)(blockIdx.x / (unsigned)col_blocks);      // (folded like k_pairwise's grid)
+    const int j = bx * 256 + threadIdx.x, bt = blockIdx.y;
     if (j >= s.n) return;
     const size_t o = ((size_t)bt * s.m + i) * s.n + j;
     P[o] = exp(((-s.M[o] + s.u[(size_t)bt * s.m + i]) + s.v[(size_t)bt * s.n + j]) / s.eps);

@@ -235,7 +235,9 @@ static int pairwise_impl(pcu_hip_ctx* c, const T* a, const T* b, int64_t nb, int
         T* dout = out;
         if (!on_dev && (rc = aalloc(ar, &dout, no))) break;
         const int pc = std::isnan(p_norm) ? P_TWO : pcode_of(p_norm);                 // ord=None: the 2-norm
-        hipLaunchKernelGGL((k_pairwise<T>), dim3((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4), (unsigned)nb), dim3(256), 0, s, da, db, (int)m, (int)n, (int)d, pc, p_norm, dout);
+        const long long pw_cols = (n + 63) / 64, pw_blocks = pw_cols * ((m + 3) / 4);
+        if (pw_blocks > 0x7fffffffll || nb > 65535) { rc = fail(PCU_HIP_ERR_INVALID, "pairwise_distances: problem too large (more than 2^31-1 tiles of 4 x 64 entries per batch, or more than 65535 batches)"); break; }
+        hipLaunchKernelGGL((k_pairwise<T>), dim3((unsigned)pw_blocks, (unsigned)nb), dim3(256), 0, s, da, db, (int)m, (int)n, (int)d, pc, p_norm, dout, (int)pw_cols);
         HIP_TRY(hipGetLastError());
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(T), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -304,7 +306,9 @@ static int sinkhorn_impl(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int
             }
         }
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((k_sink_plan<T>), dim3((unsigned)((n + 255) / 256), (unsigned)m, (unsigned)nb), dim3(256), 0, s, k, dP);
+        const long long pl_cols = (n + 255) / 256;
+        if (pl_cols * m > 0x7fffffffll) { rc = fail(PCU_HIP_ERR_INVALID, "sinkhorn: cost matrix too large (more than 2^31-1 row segments of 256 entries per batch)"); break; }
+        hipLaunchKernelGGL((k_sink_plan<T>), dim3((unsigned)(pl_cols * m), (unsigned)nb), dim3(256), 0, s, k, dP, (int)pl_cols);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_flags, flagsd, sizeof host_flags, hipMemcpyDeviceToHost, s));
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out_P, dP, nM * sizeof(T), hipMemcpyDeviceToHost, s));

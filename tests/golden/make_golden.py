@@ -19,9 +19,54 @@ import oracle  # noqa: E402
 REF_DATA = "/root/reference/data"
 
 
+def nonfinite_cases():
+    """Fixtures with non-finite and signed-zero coordinates (names nf_*): what the reference's nanoflann returns where its kd-tree
+    survives the input -- any query (rows with a non-finite coordinate find nothing: -1 / -1.0), datasets with -0.0, and datasets
+    whose infinities have one sign per axis. (A NaN in the dataset, or +inf and -inf along one axis, make the reference's tree
+    bounds NaN and its rows traversal-dependent: those inputs are rejected by the GPU path, tests/test_gpu_parity.py.)"""
+    rng = np.random.default_rng(20250924)
+    cases = {}
+
+    def add(name, q, r, k, squared=False):
+        d, c = oracle.knn(q, r, k, squared_distances=squared, kind="ref")
+        cases["nf_" + name] = dict(q=q, r=r, k=np.int64(k), squared=np.int64(squared), d=d, c=c)
+
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        # signed zeros: a lattice around the origin, half of the zeros negative; duplicates -> exact ties
+        g = np.stack(np.meshgrid(*[np.arange(-3, 4)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(dt)
+        gz = g.copy(); gz[(gz == 0) & (rng.random(gz.shape) < 0.5)] = -0.0
+        qz = (rng.integers(-6, 7, (300, 3)) / 2).astype(dt); qz[(qz == 0) & (rng.random(qz.shape) < 0.5)] = -0.0
+        add(f"negzero_k3_{tag}", qz, np.concatenate([gz, g[::3]]), 3)
+        q = rng.random((700, 3), dtype=dt); r = rng.random((1100, 3), dtype=dt)
+        qi = q.copy(); qi[5, 0] = np.inf; qi[17, 1] = -np.inf; qi[40] = [np.inf, np.inf, -np.inf]; qi[699, 2] = np.inf
+        add(f"inf_query_k1_{tag}", qi, r, 1)
+        add(f"inf_query_k3_{tag}", qi, r, 3, squared=True)
+        qn = q.copy(); qn[0, 1] = np.nan; qn[33] = np.nan; qn[500, 2] = np.nan; qn[501, 0] = np.inf
+        add(f"nan_query_k1_{tag}", qn, r, 1)
+        add(f"nan_query_k4_{tag}", qn, r, 4)
+        rp = r.copy(); rp[0, 2] = np.inf; rp[7, 0] = np.inf; rp[400] = np.inf; rp[1099, 1] = np.inf
+        add(f"pinf_dataset_k1_{tag}", q, rp, 1)
+        add(f"pinf_dataset_k5_{tag}", qn, rp, 5)
+        rm = r.copy(); rm[3, 0] = np.inf; rm[9, 1] = -np.inf; rm[10, 1] = -np.inf; rm[800, 2] = np.inf
+        add(f"mixed_axes_inf_dataset_k2_{tag}", q, rm, 2)
+        add(f"all_inf_column_k1_{tag}", q[:200], np.concatenate([r[:300, :2], np.full((300, 1), -np.inf, dt)], 1), 1)
+    for name, c in cases.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)
+    print("wrote", len(cases), "non-finite fixtures")
+    # BASELINE config 1: chamfer_distance of two 10k-point fp64 clouds through the reference's CPU path (inputs are seeded, not stored)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cloud
+    x, y = cloud(1000, 10_000, np.float64), cloud(1001, 10_000, np.float64)
+    ch, cxy, cyx = oracle.chamfer_distance(x, y, return_index=True, kind="ref")
+    np.savez_compressed(os.path.join(HERE, "config1.npz"), chamfer=np.float64(ch), cxy=cxy, cyx=cyx)
+
+
 def main():
     oracle.build()
     assert oracle.have_ref(), "needs /root/reference (oracle/_ref)"
+    if "--only-nonfinite" in sys.argv:
+        return nonfinite_cases()
+    nonfinite_cases()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import read_ply_vertices
     rng = np.random.default_rng(20250321)

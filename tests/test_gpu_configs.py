@@ -151,34 +151,57 @@ def test_squeeze_of_singleton_shapes(pcu):
     assert d.shape == (3,) and c.shape == (3,)
 
 
+SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINUE=1", "PCU_HIP_NO_SPIN=1", "PCU_HIP_NO_GRAPH=1",
+            "PCU_HIP_NO_KD_SPEC=1", "PCU_HIP_NO_RESCALE=1", "PCU_HIP_KD_FULL=1", "PCU_HIP_NO_K1=1", "PCU_HIP_INDEX=atomic",
+            "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1"]
+
+
 @pytest.mark.gpu
-def test_opt_in_balanced_lane_pass_is_identical(pcu, tmp_path):
-    """PCU_HIP_BAL=1 selects the work-queue variant of the k = 1 lane pass (search.h: search1_bal_body). It is opt-in because it
-    is not faster, but it must return the same bits: indices, distances, Chamfer and Hausdorff values of a run with the variable
-    set (a child process: the switch is read once) are compared with this process's results."""
+@pytest.mark.parametrize("switch", SWITCHES)
+def test_every_environment_switch_keeps_the_results(pcu, oracle_kind, tmp_path, switch):
+    """Every environment switch the library reads (fallback pipelines and diagnostics; each is read once per process, hence a child
+    process per switch) must leave the results untouched: a uniform pair with duplicated rows (exact ties -> tie-order resolver),
+    a pair with a tight cluster and a far outlier (give-ups, refit, stragglers) and a small dense Sinkhorn problem, against the
+    oracle / this process's default run."""
     import subprocess
     import sys
-    rng = np.random.default_rng(77)
-    x = rng.random((200_000, 3), dtype=np.float32)
-    y = rng.random((150_000, 3), dtype=np.float32)
-    y[:500] = x[:500]                                   # exact zeros and exact ties (duplicated rows)
-    y[500:1000] = y[1000:1500]
-    np.save(tmp_path / "x.npy", x); np.save(tmp_path / "y.npy", y)
+    rng = np.random.default_rng(91)
+    x = rng.random((70_000, 3), dtype=np.float32); y = rng.random((60_000, 3), dtype=np.float32)
+    y[:400] = x[:400]; y[400:800] = y[800:1200]
+    cx = np.concatenate([rng.random((40_000, 3)), rng.normal(0.5, 0.002, (8_000, 3))]).astype(np.float32); cx[0] = [40.0, -30.0, 20.0]
+    cy = np.concatenate([rng.random((30_000, 3)), rng.normal(0.5, 0.002, (9_000, 3))]).astype(np.float32)
+    np.savez(tmp_path / "in.npz", x=x, y=y, cx=cx, cy=cy)
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
-        "x = np.load(%r); y = np.load(%r)\n"
-        "d, i = pcu.k_nearest_neighbors(x, y, 1)\n"
-        "h = pcu.hausdorff_distance(x, y, return_index=True)\n"
-        "c = pcu.chamfer_distance(x, y)\n"
-        "np.savez(%r, d=d, i=i, h=np.array(h, dtype=np.float64), c=np.float64(c))\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "x.npy"), str(tmp_path / "y.npy"), str(tmp_path / "out.npz"))
-    env = dict(os.environ, PCU_HIP_BAL="1")
-    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        "g = np.load(%r); x, y, cx, cy = g['x'], g['y'], g['cx'], g['cy']\n"
+        "out = {}\n"
+        "for rep in range(2):\n"
+        "    for tag, a, b in (('u', x, y), ('c', cx, cy)):\n"
+        "        out[tag + 'd1'], out[tag + 'i1'] = pcu.k_nearest_neighbors(a, b, 1)\n"
+        "        out[tag + 'd5'], out[tag + 'i5'] = pcu.k_nearest_neighbors(a, b, 5)\n"
+        "        out[tag + 'h'] = np.array(pcu.hausdorff_distance(a, b, return_index=True), dtype=np.float64)\n"
+        "        out[tag + 'c'] = np.float64(pcu.chamfer_distance(a, b))\n"
+        "        c, cxy, cyx = pcu.chamfer_distance(a, b, return_index=True); out[tag + 'cxy'] = cxy; out[tag + 'cyx'] = cyx\n"
+        "M = pcu.pairwise_distances(x[:700], y[:600]); w = np.full(700, 1 / 700, np.float32); v = np.full(600, 1 / 600, np.float32)\n"
+        "out['P'] = pcu.sinkhorn(w, v, M, eps=1e-2, max_iters=30, stop_thresh=0.0)\n"
+        "np.savez(%r, **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), str(tmp_path / "out.npz"))
+    name, value = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{name: value}), timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(tmp_path / "out.npz")
-    d, i = pcu.k_nearest_neighbors(x, y, 1)
-    assert np.array_equal(got["i"], i) and np.array_equal(got["d"].view(np.uint32), np.asarray(d).view(np.uint32))
-    assert np.array_equal(got["h"], np.array(pcu.hausdorff_distance(x, y, return_index=True), dtype=np.float64))
-    assert float(got["c"]) == float(pcu.chamfer_distance(x, y))
+    for tag, a, b in (("u", x, y), ("c", cx, cy)):
+        for k in (1, 5):
+            d0, i0 = oracle.k_nearest_neighbors(a, b, k, kind=oracle_kind)
+            assert np.array_equal(got[f"{tag}i{k}"], i0), (switch, tag, k)
+            assert np.array_equal(got[f"{tag}d{k}"].view(np.uint32), np.asarray(d0).view(np.uint32)), (switch, tag, k)
+        assert tuple(got[tag + "h"]) == tuple(float(v) for v in oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind)), (switch, tag)
+        c0, cxy0, cyx0 = oracle.chamfer_distance(a, b, return_index=True, kind=oracle_kind)
+        assert np.array_equal(got[tag + "cxy"], cxy0) and np.array_equal(got[tag + "cyx"], cyx0), (switch, tag)
+        assert abs(float(got[tag + "c"]) - float(c0)) <= 1e-4 * float(c0), (switch, tag)
+    M = pcu.pairwise_distances(x[:700], y[:600]); w = np.full(700, 1 / 700, np.float32); v = np.full(600, 1 / 600, np.float32)
+    P = pcu.sinkhorn(w, v, M, eps=1e-2, max_iters=30, stop_thresh=0.0)
+    assert np.abs(got["P"] - P).max() <= 2e-4 * np.abs(P).max(), switch
 
 
 @pytest.mark.gpu
@@ -301,3 +324,18 @@ def test_poisoned_workspace_on_passes_that_give_up(pcu, oracle_kind, tmp_path):
     for got_v, p in zip(v, (1, 3, np.inf)):
         v0 = float(oracle.chamfer_distance(g1, g2, p_norm=p, kind=oracle_kind))
         assert abs(got_v - v0) <= 1e-4 * v0
+
+
+def test_config1_chamfer_10k_f64(pcu, oracle_kind):
+    """BASELINE config 1, literally: chamfer_distance on two 10k-point fp64 U[0,1)^3 clouds (seeds 1000 / 1001) -- the
+    reference's nanoflann CPU path gives the expected value and both index arrays; the GPU path must reproduce them (value within
+    1e-6, indices exact). The CPU-only half (reference against the restatement) is tests/test_oracle.py::test_config1_cpu."""
+    x, y = cloud(1000, 10_000, np.float64), cloud(1001, 10_000, np.float64)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=oracle_kind)
+    ch, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)
+    assert type(ch) == np.float64 and np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch) - float(ch0)) <= 1e-6 * float(ch0)
+    assert abs(float(pcu.chamfer_distance(x, y)) - float(ch0)) <= 1e-6 * float(ch0)
+    for p in (1, np.inf):
+        v0 = oracle.chamfer_distance(x, y, p_norm=p, kind=oracle_kind)
+        assert abs(float(pcu.chamfer_distance(x, y, p_norm=p)) - float(v0)) <= 1e-6 * float(v0)

@@ -14,7 +14,7 @@ from conftest import cloud
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith(("metrics.npz", "sinkhorn.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith(("metrics.npz", "sinkhorn.npz", "config1.npz")))
 # fixtures whose expected order of exact ties is the kd-tree traversal order
 TIE_CASES = ("duplicates", "self_k3", "lattice", "dup_self", "bunny_vs_dup")
 
@@ -437,3 +437,84 @@ def test_torch_inputs_produced_on_the_current_stream(pcu):
         assert torch.equal(c, c2) and torch.equal(d, d2)
         bb = b[c]
         assert torch.allclose(d, (a - bb).norm(dim=1), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_nonfinite_inputs(pcu, oracle_kind, dtype):
+    """NaN / inf coordinates (golden fixtures nf_* cover the small sizes): query rows with a non-finite coordinate find nothing
+    (-1 / -1.0, src/point_cloud_distance.cpp:90-93 via nanoflann.hpp:1563), dataset points with a single-signed infinity are never a
+    neighbour -- as the reference, at sizes that take the lane-per-query kernels. What breaks the reference's kd-tree (NaN in the
+    dataset, +inf and -inf along one axis: its bounds become NaN and its rows depend on the traversal) raises ValueError, and so
+    does any non-finite coordinate in chamfer_distance / hausdorff_distance (the reference pairs such rows through index -1)."""
+    rng = np.random.default_rng(77)
+    n, m = 120_000, 90_000
+    q = rng.random((n, 3)).astype(dtype); r = rng.random((m, 3)).astype(dtype)
+    q[rng.integers(0, n, 40), rng.integers(0, 3, 40)] = np.nan
+    q[rng.integers(0, n, 40), rng.integers(0, 3, 40)] = np.inf
+    q[rng.integers(0, n, 40), rng.integers(0, 3, 40)] = -np.inf
+    r[rng.integers(0, m, 25), 0] = np.inf; r[rng.integers(0, m, 25), 2] = -np.inf; r[0, 0] = np.inf
+    for k in (1, 4):
+        d, c = pcu.k_nearest_neighbors(q, r, k)
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+        assert np.array_equal(c, c0), pcu.last_stats()
+        assert np.array_equal(d.view(np.uint8), d0.view(np.uint8))
+        assert (c0 == -1).any() and (c0[~np.isfinite(q).all(1)] == -1).all()
+    with pcu.DatasetIndex(r) as index:
+        d, c = index.k_nearest_neighbors(q[:30000], 2)
+        d0, c0 = oracle.k_nearest_neighbors(q[:30000], r, 2, kind=oracle_kind)
+        assert np.array_equal(c, c0) and np.array_equal(d.view(np.uint8), d0.view(np.uint8))
+    ok = rng.random((50_000, 3)).astype(dtype)
+    for bad in ("nan", "both_inf"):
+        rb = rng.random((m, 3)).astype(dtype)
+        if bad == "nan": rb[1234, 1] = np.nan
+        else: rb[5, 2] = np.inf; rb[70000, 2] = -np.inf
+        for qq in (ok, ok[:500]):                       # lane-per-query and wave-per-query entry
+            with pytest.raises(ValueError, match="NaN coordinates"):
+                pcu.k_nearest_neighbors(qq, rb, 1)
+        with pytest.raises(ValueError, match="NaN coordinates"):
+            pcu.k_nearest_neighbors(ok[:100], rb, 200)  # k > 127: the kd-tree path
+        with pytest.raises(ValueError, match="NaN coordinates"):
+            pcu.DatasetIndex(rb)
+    for a, b in ((q[:60000], ok), (ok, r), (ok[:300], r[:2000])):
+        for fn in (pcu.chamfer_distance, pcu.hausdorff_distance, pcu.one_sided_hausdorff_distance,
+                   lambda x, y: pcu.chamfer_distance(x, y, return_index=True), lambda x, y: pcu.chamfer_distance(x, y, p_norm=1)):
+            with pytest.raises(ValueError, match="non-finite"):
+                fn(a, b)
+    # the context is as good as new afterwards
+    d, c = pcu.k_nearest_neighbors(ok, ok[:40000], 1)
+    d0, c0 = oracle.k_nearest_neighbors(ok, ok[:40000], 1, kind=oracle_kind)
+    assert np.array_equal(c, c0) and np.array_equal(d, d0)
+    assert float(pcu.chamfer_distance(ok, ok[:40000])) > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("leaf", [1, 33])
+def test_max_points_per_leaf_decides_tie_order(pcu, oracle_kind, dtype, leaf):
+    """max_points_per_leaf is forwarded to the reference's tree (src/point_cloud_distance.cpp:41; leaf test nanoflann.hpp:1008) and
+    changes which of several exactly tied points is met first. Through the public API on duplicated points and on a lattice, for
+    leaf sizes other than the default: rows equal the reference's built with the same leaf size (and differ from leaf 10 somewhere,
+    i.e. the argument is not ignored)."""
+    rng = np.random.default_rng(5)
+    base = rng.random((20000, 3)).astype(dtype)
+    dup = np.concatenate([base, base[::2], base[::3]])                      # every point 1-3 times
+    lat = np.stack(np.meshgrid(*[np.arange(24)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(dtype)
+    qlat = (rng.integers(0, 47, (30000, 3)) / 2).astype(dtype)              # on lattice points and half way between them
+    differs = False
+    for q, r, k in ((base[:15000], dup, 1), (base[:15000], dup, 3), (qlat, lat, 1), (qlat, lat, 6), (dup, dup, 2)):
+        d, c = pcu.k_nearest_neighbors(q, r, k, max_points_per_leaf=leaf)
+        d0, c0 = oracle.k_nearest_neighbors(q, r, k, max_points_per_leaf=leaf, kind=oracle_kind)
+        assert np.array_equal(c, c0), (k, pcu.last_stats())
+        assert np.array_equal(d, d0)
+        _, c10 = oracle.k_nearest_neighbors(q, r, k, max_points_per_leaf=10, kind=oracle_kind)
+        differs = differs or not np.array_equal(c0, c10)
+    assert differs
+    x, y = base[:15000], dup
+    ch, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True, max_points_per_leaf=leaf)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, max_points_per_leaf=leaf, kind=oracle_kind)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
+    assert abs(float(ch) - float(ch0)) <= (1e-4 if dtype == np.float32 else 1e-6) * float(ch0)
+    for a, b in ((qlat, lat), (lat, qlat)):
+        assert pcu.hausdorff_distance(a, b, return_index=True, max_points_per_leaf=leaf) == \
+            oracle.hausdorff_distance(a, b, return_index=True, max_points_per_leaf=leaf, kind=oracle_kind)
+        assert pcu.one_sided_hausdorff_distance(a, b, max_points_per_leaf=leaf) == \
+            oracle.one_sided_hausdorff_distance(a, b, max_points_per_leaf=leaf, kind=oracle_kind)

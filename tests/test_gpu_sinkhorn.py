@@ -77,3 +77,48 @@ def test_sinkhorn_vs_restatement_larger(pcu, dtype):
     import torch
     Pt = pcu.sinkhorn(torch.from_numpy(wa).cuda(), torch.from_numpy(wb).cuda(), torch.from_numpy(Mb).cuda(), eps=1e-2, max_iters=50)
     assert Pt.is_cuda and np.array_equal(Pt.cpu().numpy(), Pb)                 # device-resident inputs: same kernels, same bits
+
+
+def test_forbidden_assignments_and_zero_weights(pcu):
+    """M = +inf entries (forbidden assignments) and zero weights (log a = -inf -> u = -inf): the column update's streaming
+    log-sum-exp meets x = -inf while its running maximum is still -inf. The reference subtracts the column maximum first and gets
+    exp(-inf) = 0 (point_cloud_utils/_sinkhorn.py:86-117); so must both pipelines (single-read k_sink_iter and the two-pass
+    k_sink_rows / k_sink_cols), wherever the row falls in a block's slab."""
+    rng = np.random.default_rng(3)
+    for dtype, rt in ((np.float32, 5e-4), (np.float64, 1e-8)):
+        for m, n in ((96, 80), (300, 5000)):                       # n <= 4096: k_sink_iter; wider: rows + column slabs
+            a = rng.random((m, 3)).astype(dtype); b = rng.random((n, 3)).astype(dtype)
+            M = pcu.pairwise_distances(a, b).copy()
+            M[0, :7] = np.inf; M[5, 3] = np.inf; M[m - 1, n - 1] = np.inf; M[8:16, 11] = np.inf     # first row of a slab, and inside one
+            wa = np.full(m, 1.0 / (m - 2), dtype); wa[0] = 0; wa[17] = 0                        # zero weights incl. the first row
+            wb = np.full(n, 1.0 / n, dtype)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                P0, _ = oracle.sinkhorn(wa, wb, M, 1e-2, 40, 0.0)
+            assert np.isfinite(P0).all()
+            P = pcu.sinkhorn(wa, wb, M, eps=1e-2, max_iters=40, stop_thresh=0.0)
+            assert np.isfinite(P).all(), (dtype, m, n)
+            _close(P, P0.astype(dtype), rt)
+            assert (P[0] == 0).all() and P[5, 3] == 0
+
+
+def test_more_rows_than_a_grid_dimension_and_broadcast_inputs(pcu):
+    """100k points against 100 centroids (more rows than gridDim.y allows), and the inputs the reference's numpy expression accepts:
+    a batch of one against a batch of m, d = 1 against d, integer and mixed-precision arrays (numpy promotion)."""
+    rng = np.random.default_rng(4)
+    a = rng.random((100_000, 3)).astype(np.float32); b = rng.random((100, 3)).astype(np.float32)
+    M = pcu.pairwise_distances(a, b)
+    sel = rng.choice(100_000, 2000, replace=False)
+    _close(M[sel], oracle.pairwise_distances(a[sel], b), 2e-6)
+    wa = np.full(100_000, 1e-5, np.float32); wb = np.full(100, 1e-2, np.float32)
+    P = pcu.sinkhorn(wa, wb, M, eps=5e-2, max_iters=10, stop_thresh=0.0)
+    P0, _ = oracle.sinkhorn(wa, wb, M, 5e-2, 10, 0.0)
+    _close(P, P0, 5e-4)
+    ab = rng.random((1, 40, 3)); bb = rng.random((5, 30, 3))
+    for x, y in ((ab, bb), (bb, ab), (rng.random((5, 40, 1)), bb), (rng.integers(0, 9, (5, 40, 3)), bb),
+                 (ab.astype(np.float32), bb), (rng.integers(0, 9, (40, 3)), rng.integers(0, 9, (30, 3)).astype(np.int32))):
+        ref = np.linalg.norm(x[..., :, None, :] - y[..., None, :, :], axis=-1)
+        got = pcu.pairwise_distances(x, y)
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ValueError, match="broadcast"):
+        pcu.pairwise_distances(rng.random((2, 4, 3)), rng.random((3, 4, 3)))

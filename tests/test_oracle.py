@@ -10,7 +10,7 @@ import oracle
 from conftest import cloud
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith(("metrics.npz", "sinkhorn.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "*.npz")) if not p.endswith(("metrics.npz", "sinkhorn.npz", "config1.npz")))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
@@ -152,3 +152,16 @@ def test_oracle_sinkhorn_pinned_to_reference_module_and_golden():
         assert np.array_equal(M, oracle.pairwise_distances(x, y, 2))
         wa = np.full((2, 30), 1 / 30, np.float32); wb = np.full((2, 25), 1 / 25, np.float32)
         assert np.array_equal(ref.sinkhorn(wa, wb, M, 1e-2), oracle.sinkhorn(wa, wb, M, 1e-2)[0])
+
+
+def test_config1_cpu():
+    """BASELINE config 1 ("chamfer_distance on two 10k-point fp64 random clouds via reference nanoflann CPU path; plumbing, no GPU"):
+    the reference's nanoflann (oracle/_ref, where built) and the restatement agree bit for bit on value and correspondences, and a
+    golden scalar generated from the reference (tests/golden/make_golden.py) pins both."""
+    x, y = cloud(1000, 10_000, np.float64), cloud(1001, 10_000, np.float64)
+    ch, cxy, cyx = oracle.chamfer_distance(x, y, return_index=True, kind="port")
+    g = np.load(os.path.join(GOLD, "config1.npz"))
+    assert float(ch) == float(g["chamfer"]) and np.array_equal(cxy, g["cxy"]) and np.array_equal(cyx, g["cyx"])
+    if oracle.have_ref():
+        ch1, cxy1, cyx1 = oracle.chamfer_distance(x, y, return_index=True, kind="ref")
+        assert float(ch1) == float(ch) and np.array_equal(cxy1, cxy) and np.array_equal(cyx1, cyx)
