@@ -57,7 +57,16 @@ __device__ __forceinline__ bool take_ticket(unsigned* ticket, unsigned nblocks) 
 #define PCU_BBOX_BLOCKS 256
 #endif
 constexpr int kBboxBlocks = PCU_BBOX_BLOCKS;   // one per CU; partial[b][0..2] = min xyz, [3..5] = max xyz (finite values only), [6] = non-finite flags
-constexpr int kBboxStride = 8;                 // values per partial
+constexpr int kBboxStride = 16;                // values per partial: [0..2] min, [3..5] max, [6] non-finite flags, [7] finite points, [8..10] sum (v - pivot), [11..13] sum (v - pivot)^2
+// Robust grid range. The grid is laid over [max(min, mean - kCoreSigmas sigma), min(max, mean + kCoreSigmas sigma)] per axis instead of
+// the exact bounding box: a few stray points far from the cloud (real scans have them) would otherwise inflate the box until the
+// whole cloud sits in a handful of cells -- the first build then died in per-cell atomics (1.2 ms for 1M points) and the call went
+// through the refit machinery (2.3 ms against 0.17 ms). Points beyond the range are held by the border cells (cell_coord clamps; the
+// searches know: GridParams::org, face_lower_bound), the exact box stays in gmin / gmax for the certification. Clouds that fill
+// their box (uniform, surfaces, two far clusters: box within mean +- 1.8 sigma) keep exactly the box. The moments are taken
+// relative to the cloud's first point (cancellation: a cloud at 1000 +- 0.001) and are a heuristic only: the grid decides which
+// candidates a query looks at, never a result.
+constexpr double kCoreSigmas = 3.0;
 // Non-finite coordinates (k_bbox_partial -> GridParams::nonfinite). The bounding box -- hence the grid -- is laid over the FINITE values;
 // points with a non-finite coordinate sit in border cells (cell_coord clamps) and their d2 is +inf or NaN, which never beats a
 // neighbour (strict '<' against a k-th best that starts at FLT_MAX): exactly what the reference's result set does with them
@@ -77,6 +86,9 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     unsigned nf = 0;          // bit 0: NaN seen; bits 1..3: +inf on axis j; bits 4..6: -inf on axis j
     auto classify = [&](T v, int j) { nf |= v != v ? 1u : (v > (T)0 ? (2u << j) : (16u << j)); };
+    T piv[3], s1[3] = {(T)0, (T)0, (T)0}, s2[3] = {(T)0, (T)0, (T)0}, cnt = (T)0;       // moments of the finite points about the cloud's first point
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const T v = pts[j]; piv[j] = ((v < (T)0 ? -v : v) <= Limits<T>::max_v) ? v : (T)0; }
     // four points = 12 consecutive scalars = three 16-byte (f32) loads per trip, all in flight together; a plain
     // point-per-trip loop waits for memory 15 times per thread at n = 1M
     struct __attribute__((packed, aligned(4))) Vec4 { T v[4]; };
@@ -93,7 +105,10 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
             all_fin = all_fin && fin;
             lo[k % 3] = (fin && v[k] < lo[k % 3]) ? v[k] : lo[k % 3];
             hi[k % 3] = (fin && v[k] > hi[k % 3]) ? v[k] : hi[k % 3];
+            const T dv = fin ? v[k] - piv[k % 3] : (T)0;
+            s1[k % 3] += dv; s2[k % 3] += dv * dv;
         }
+        cnt += (T)4;
         if (!all_fin) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) if (!((v[k] < (T)0 ? -v[k] : v[k]) <= Limits<T>::max_v)) classify(v[k], k % 3);
@@ -108,7 +123,10 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
             if (!fin) classify(v, j);
             lo[j] = (fin && v < lo[j]) ? v : lo[j];
             hi[j] = (fin && v > hi[j]) ? v : hi[j];
+            const T dv = fin ? v - piv[j] : (T)0;
+            s1[j] += dv; s2[j] += dv * dv;
         }
+        cnt += (T)1;
     }
     {   // zero-fill (16-byte stores; `counts` is 256-byte aligned arena memory)
         uint4* c4 = reinterpret_cast<uint4*>(counts);
@@ -117,13 +135,22 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
         if (gtid < (n_counts & 3)) counts[(m4 << 2) + gtid] = 0u;
         for (int i = gtid; i < n_zero2; i += gstride) zero2[i] = 0u;
     }
-    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
+    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3], s_mom[kBlock / 64][7];
     __shared__ unsigned s_nf[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         T a = wave_min(lo[j]), b = wave_max(hi[j]);
         if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = b; }
+    }
+    {
+        T m[7] = {cnt, s1[0], s1[1], s1[2], s2[0], s2[1], s2[2]};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m[q] += __shfl_xor(m[q], o, 64);
+            if (lane == 0) s_mom[wave][q] = m[q];
+        }
     }
     {
         unsigned m = 0;
@@ -142,6 +169,11 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
         unsigned m = 0;
         for (int w = 0; w < kBlock / 64; ++w) m |= s_nf[w];
         publish(&partial[bid * kBboxStride + 6], (T)m);       // (<= 127: exact in T)
+    } else if (threadIdx.x >= 4 && threadIdx.x < 11) {
+        const int q = threadIdx.x - 4;
+        T a = s_mom[0][q];
+        for (int w = 1; w < kBlock / 64; ++w) a += s_mom[w][q];
+        publish(&partial[bid * kBboxStride + 7 + q], a);
     }
 }
 
@@ -149,32 +181,43 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
 // n = 0 gets no blocks). The build passes are latency-bound (1-3 TB/s), so two clouds per launch cost far less than two
 // launches, and the launch count of a two-sided call halves.
 template <typename T>
-struct BboxSide { const T* pts; int n; T* partial; unsigned* counts; int n_counts; unsigned* zero2; int n_zero2; };
+struct BboxSide { const T* pts; int n; T* partial; unsigned* counts; int n_counts; unsigned* zero2; int n_zero2; GridParams<T>* gp; };
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bbox_partial(const BboxSide<T> a0, const BboxSide<T> a1, int nb0) {
     const bool second = (int)blockIdx.x >= nb0;
     const BboxSide<T>& a = second ? a1 : a0;
-    bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, second ? (int)blockIdx.x - nb0 : (int)blockIdx.x,
-                 second ? (int)gridDim.x - nb0 : nb0);
+    const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
+    if (bid == 0 && threadIdx.x == 0) { a.gp->sumsq = 0ull; a.gp->has_large = 0; }        // (the accumulators: every later kernel of the build adds to / raises them)
+    bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, bid, second ? (int)gridDim.x - nb0 : nb0);
 }
 
 // One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
-template <typename T>
-__device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel, double h_want = 0.0) {
-    __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
-    __shared__ unsigned s_nf[kBlock / 64];
+// NT = threads of the calling block. `gp` may be a block's private copy in LDS (k_bucket_onepass: every block lays out the grid itself,
+// which saves the k_make_grid launch): with accumulators = false the fields other kernels accumulate into or raise -- sumsq, has_large,
+// zeroed by k_bbox_partial -- and the sentinel records are left alone.
+// (The partials come from an earlier launch: plain loads. With agent-scope loads -- which bypass the L1 -- the 490 blocks of a
+// one-pass build hammered the 14 cache lines of the partials in L2 and the layout cost 7.6 us per block instead of ~2.)
+template <typename T, int NT>
+__device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __restrict__ partial, int nparts, int n, double occupancy, int max_cells, Pt4<T>* sentinel, double h_want = 0.0,
+                                               bool accumulators = true, const T* __restrict__ pivot = nullptr) {
+    __shared__ T s_lo[NT / 64][3], s_hi[NT / 64][3];
+    __shared__ double s_mom[NT / 64][7];
+    __shared__ unsigned s_nf[NT / 64];
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
         T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
+        double mom[7] = {0, 0, 0, 0, 0, 0, 0};
         unsigned nf = 0;
-        for (int b = threadIdx.x; b < nparts; b += kBlock) {
+        for (int b = threadIdx.x; b < nparts; b += NT) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                T a = peek(&partial[b * kBboxStride + j]), c = peek(&partial[b * kBboxStride + 3 + j]);
+                T a = partial[b * kBboxStride + j], c = partial[b * kBboxStride + 3 + j];
                 lo[j] = a < lo[j] ? a : lo[j]; hi[j] = c > hi[j] ? c : hi[j];
             }
-            nf |= (unsigned)peek(&partial[b * kBboxStride + 6]);
+            nf |= (unsigned)partial[b * kBboxStride + 6];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) mom[q] += (double)partial[b * kBboxStride + 7 + q];
         }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -182,6 +225,14 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
             T a = wave_min(lo[j]), c = wave_max(hi[j]);
             if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = c; }
         }
+        if (wave < (nparts + 63) / 64) {            // (waves without partials hold zeros)
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mom[q] += __shfl_xor(mom[q], o, 64);
+            }
+        }
+        if (lane == 0) for (int q = 0; q < 7; ++q) s_mom[wave][q] = mom[q];
         unsigned m = 0;
 #pragma unroll
         for (int b = 0; b < 7; ++b) if (__ballot((nf >> b) & 1u)) m |= 1u << b;
@@ -191,18 +242,30 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
     if (threadIdx.x != 0) return;
     {
         unsigned m = 0;
-        for (int w = 0; w < kBlock / 64; ++w) m |= s_nf[w];
+        for (int w = 0; w < NT / 64; ++w) m |= s_nf[w];
         const unsigned pinf = (m >> 1) & 7u, ninf = (m >> 4) & 7u;
-        gp->nonfinite = ((m & 1u) ? kNfNaN : 0) | ((pinf & ninf) ? kNfBothInf : 0) | ((pinf | ninf) ? kNfAnyInf : 0);
+        gp->nonfinite = ((m & 1u) ? kNfNaN : 0) | ((pinf & ninf) ? kNfBothInf : 0) | ((pinf | ninf) ? kNfAnyInf : 0) | (int)(m << 8);      // (bits 8..14: the raw mask, for the kd-tree's root box)
     }
-    if (sentinel) for (int j = 0; j < 8; ++j) { sentinel[j].x = sentinel[j].y = sentinel[j].z = (T)INFINITY; sentinel[j].idx = 0x7fffffff; }   // records n..n+7: see k_search / k_search1
-    double ext[3];
+    if (sentinel) put_sentinels(sentinel - n, n);
+    double ext[3], mom[7] = {0, 0, 0, 0, 0, 0, 0};
+    T rlo[3], rhi[3];                               // the range the grid is laid over (see kCoreSigmas)
+    for (int w = 0; w < (nparts + 63) / 64 && w < NT / 64; ++w) for (int q = 0; q < 7; ++q) mom[q] += s_mom[w][q];
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];
-        for (int w = 1; w < kBlock / 64; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
+        for (int w = 1; w < NT / 64; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
         if (!(lo <= hi)) { lo = 0; hi = 0; }      // no finite value in this column
         gp->gmin[j] = lo; gp->gmax[j] = hi;
-        ext[j] = (double)hi - (double)lo;
+        rlo[j] = lo; rhi[j] = hi;
+        if (pivot && mom[0] > 0) {
+            T pv = pivot[j]; if (!((pv < (T)0 ? -pv : pv) <= Limits<T>::max_v)) pv = (T)0;
+            const double m1 = mom[1 + j] / mom[0], var = mom[4 + j] / mom[0] - m1 * m1, sd = var > 0 ? sqrt(var) : 0.0, mu = (double)pv + m1;
+            const T a = (T)(mu - kCoreSigmas * sd), b = (T)(mu + kCoreSigmas * sd);
+            if (a <= b) {                         // (moments that overflowed give NaN: the exact box stands)
+                if (a > rlo[j] && a < hi) rlo[j] = a;
+                if (b < rhi[j] && b > rlo[j]) rhi[j] = b;
+            }
+        }
+        ext[j] = (double)rhi[j] - (double)rlo[j];
     }
     double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
     double want = (double)n / (occupancy > 0 ? occupancy : 1.0);
@@ -214,7 +277,11 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
         // active axes: extent not negligible against the largest one
         bool act[3]; int nd = 0; double vol = 1.0;
         for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
-        h = pow(vol / want, 1.0 / nd);
+        // (single precision for the root: this runs serially on one thread and any h near the target will do -- the grid only decides which
+        // candidates a query looks at; every block of a one-pass build computes the same value from the same inputs)
+        const float ratio = (float)(vol / want);
+        h = (double)(nd == 3 ? cbrtf(ratio) : (nd == 2 ? sqrtf(ratio) : ratio));
+        if (!(h > 0.0) || !isfinite(h)) h = pow(vol / want, 1.0 / nd);          // (ratio outside the float range)
         if (h_want > 0 && h_want > h) h = h_want;             // fixed-radius searches (normals.h): cells no smaller than asked for
         for (int it = 0; it < 400; ++it) {
             double cells = 1.0;
@@ -233,19 +300,20 @@ __device__ void make_grid_body(GridParams<T>* gp, const T* partial, int nparts, 
     gp->inv_h = (T)1 / gp->h;
     for (int j = 0; j < 3; ++j) {
         gp->G[j] = G[j];
-        double scale = fabs((double)gp->gmin[j]) + fabs((double)gp->gmax[j]) + (double)G[j] * h;
+        double scale = fabs((double)rlo[j]) + fabs((double)rhi[j]) + (double)G[j] * h;
         gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
     }
     gp->ncells = G[0] * G[1] * G[2];
-    for (int j = 0; j < 3; ++j) gp->org[j] = gp->gmin[j];
-    gp->sumsq = 0ull; gp->closed = 0; gp->has_large = 0;
+    for (int j = 0; j < 3; ++j) gp->org[j] = rlo[j];
+    gp->closed = 0;
+    if (accumulators) { gp->sumsq = 0ull; gp->has_large = 0; }
 }
 template <typename T>
-struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; double h_want; };
+struct GridSide { GridParams<T>* gp; const T* partial; int nparts; int n; double occupancy; int max_cells; Pt4<T>* sentinel; double h_want; const T* pts; };
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_make_grid(const GridSide<T> a0, const GridSide<T> a1) {      // one block per side
     const GridSide<T>& a = blockIdx.x ? a1 : a0;
-    make_grid_body<T>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel, a.h_want);
+    make_grid_body<T, kBlock>(a.gp, a.partial, a.nparts, a.n, a.occupancy, a.max_cells, a.sentinel, a.h_want, true, a.pts);
 }
 
 // Cell id + rank-in-cell of every point. The ranks come from a returning atomicAdd on the cell's counter, and those
@@ -397,6 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const T* __restrict__ pts, i
     p.x = pts[3 * (size_t)i]; p.y = pts[3 * (size_t)i + 1]; p.z = pts[3 * (size_t)i + 2]; p.idx = i;
     const unsigned pos = cell_start[cell_of[i]] + rank[i];
     sorted[pos] = p;
+    put_xyz(sorted, n, pos, p);
     rank[i] = pos;
 }
 
@@ -541,23 +610,35 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_count(const BucketSide<T>
 // with the two-pass pipeline and keeps to it for this context (pcu_hip.hip: search_finish).
 template <typename T>
 __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __restrict__ pts, int n, GridParams<T>* gp, int shift, unsigned* fill,
-                                                   Pt4<T>* __restrict__ tmp, const unsigned cap, long long* prof) {
+                                                   Pt4<T>* __restrict__ tmp, const unsigned cap, long long* prof, const GridSide<T>& gs) {
     // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
     long long t_prev = prof ? wall_clock64() : 0;
 #define OP_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
     __shared__ unsigned s_cnt[kBkMaxBuckets];      // the block's count per bucket, then the slot position of its first record
-    const GridParams<T>& g = *gp;
-    const int NB = (g.ncells + (1 << shift) - 1) >> shift;
-    for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
-    __syncthreads();
+    __shared__ GridParams<T> s_gp;
     const int base = bid * kBkBlockPts;
-    T px[kBkPts], py[kBkPts], pz[kBkPts];
+    T px[kBkPts], py[kBkPts], pz[kBkPts];          // (the point loads do not need the grid: requested first, in flight during the layout)
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
         const int i = min(base + j * kBkThreads + (int)threadIdx.x, n - 1);
         px[j] = pts[3 * (size_t)i]; py[j] = pts[3 * (size_t)i + 1]; pz[j] = pts[3 * (size_t)i + 2];
     }
-    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OP_PROF(0); }          // head: zero + point loads
+    // Every block folds the bbox partials and lays out the grid for itself (identical arithmetic on identical inputs: identical grids);
+    // the side's first block also publishes it for the kernels that follow. One launch (k_make_grid, ~5 us of launch boundary + a
+    // serial layout on an otherwise idle chip) less per build.
+    make_grid_body<T, kBkThreads>(&s_gp, gs.partial, gs.nparts, gs.n, gs.occupancy, gs.max_cells, nullptr, gs.h_want, /*accumulators=*/false, gs.pts);
+    if (threadIdx.x == 0 && bid == 0) {
+        GridParams<T>& o = *gp;
+        for (int j = 0; j < 3; ++j) { o.gmin[j] = s_gp.gmin[j]; o.gmax[j] = s_gp.gmax[j]; o.slack[j] = s_gp.slack[j]; o.G[j] = s_gp.G[j]; o.org[j] = s_gp.org[j]; }
+        o.h = s_gp.h; o.inv_h = s_gp.inv_h; o.ncells = s_gp.ncells; o.closed = 0; o.nonfinite = s_gp.nonfinite;
+        put_sentinels(gs.sentinel - gs.n, gs.n);
+    }
+    __syncthreads();
+    const GridParams<T>& g = s_gp;
+    const int NB = (g.ncells + (1 << shift) - 1) >> shift;
+    for (int i = threadIdx.x; i < NB; i += kBkThreads) s_cnt[i] = 0;
+    __syncthreads();
+    if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OP_PROF(0); }          // head: point loads + grid layout + zero
     unsigned bk[kBkPts], rk[kBkPts];
 #pragma unroll
     for (int j = 0; j < kBkPts; ++j) {
@@ -587,10 +668,10 @@ __device__ __forceinline__ void bucket_onepass_body(const int bid, const T* __re
 #undef OP_PROF
 }
 template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass(const BucketSide<T> a0, const BucketSide<T> a1, int nb0, long long* prof) {
+__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass(const BucketSide<T> a0, const BucketSide<T> a1, int nb0, long long* prof, const GridSide<T> g0, const GridSide<T> g1) {
     const bool second = (int)blockIdx.x >= nb0;
     const BucketSide<T>& a = second ? a1 : a0;
-    bucket_onepass_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.tmp, a.cap, prof);
+    bucket_onepass_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.pts, a.n, a.gp, a.shift, a.bucket_total, a.tmp, a.cap, prof, second ? g1 : g0);
 }
 
 template <typename T>
@@ -663,7 +744,7 @@ template <typename T>
 __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* gp, int shift, const unsigned* __restrict__ bucket_start,
                                                               const Pt4<T>* __restrict__ tmp, unsigned* cell_start, Pt4<T>* __restrict__ sorted,
                                                               unsigned* __restrict__ pos_of, unsigned* __restrict__ large_list, unsigned* n_large,
-                                                              long long* prof, const int cnt_cap, const unsigned cap, const unsigned* __restrict__ fill) {
+                                                              long long* prof, const int cnt_cap, const unsigned cap, const unsigned* __restrict__ fill, const int n_pts) {
     // diagnostics (PCU_HIP_PROF_BUILD): per-stage time of every block's thread 0, summed; 100 MHz ticks
     long long t_prev = prof ? wall_clock64() : 0;
 #define BK_PROF(slot) do { if (prof && threadIdx.x == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
@@ -788,6 +869,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
         for (unsigned i = tid; i < e - s; i += kSortThreads) {
             const Pt4<T> r = s_stage[i];
             sorted[s + i] = r;
+            put_xyz(sorted, n_pts, s + i, r);
             if (pos_of) pos_of[r.idx] = s + i;
         }
     } else {
@@ -803,6 +885,7 @@ __device__ __forceinline__ void bucket_sort_body(const int bid, GridParams<T>* g
                 if (p < e) {
                     const unsigned pos = s + s_cnt[rr[it0 + u] >> 16] + (rr[it0 + u] & 0xffffu);
                     sorted[pos] = rec[u];
+                    put_xyz(sorted, n_pts, pos, rec[u]);
                     if (pos_of) pos_of[rec[u].idx] = pos;
                 }
             }
@@ -817,7 +900,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const BucketSide<T
     const bool second = (int)blockIdx.x >= nb0;
     const BucketSide<T>& a = second ? a1 : a0;
     bucket_sort_body<T>(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, a.gp, a.shift, a.bucket_start, a.tmp, a.cell_start, a.sorted, a.pos_of,
-                        a.large_list, a.n_large, prof, cnt_cap, a.cap, a.bucket_total);
+                        a.large_list, a.n_large, prof, cnt_cap, a.cap, a.bucket_total, a.n);
 }
 template <typename T>
 static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + (size_t)kStageRecs * sizeof(Pt4<T>); }
@@ -826,7 +909,7 @@ static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + 
 template <typename T>
 struct LargeJob {
     const GridParams<T>* gp; const unsigned* bucket_start; const unsigned* large_list; const unsigned* n_large;
-    const Pt4<T>* tmp; const unsigned* rank_tmp; const unsigned* cell_start; Pt4<T>* sorted; unsigned* pos_of;
+    const Pt4<T>* tmp; const unsigned* rank_tmp; const unsigned* cell_start; Pt4<T>* sorted; unsigned* pos_of; int n_pts;
 };
 // One launch serves the indexes built back to back (both clouds of a two-sided call): njobs <= 2.
 template <typename T>
@@ -843,6 +926,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_large(const LargeJob<T> j0, c
                 const Pt4<T> rec = J.tmp[p];
                 const unsigned pos = J.cell_start[cell_linear(g, rec.x, rec.y, rec.z)] + J.rank_tmp[p];
                 J.sorted[pos] = rec;
+                put_xyz(J.sorted, J.n_pts, pos, rec);
                 if (J.pos_of) J.pos_of[rec.idx] = pos;
             }
         }
@@ -939,10 +1023,10 @@ __global__ __launch_bounds__(64) void k_quant_zoom(QuantState<T>* qs, const unsi
 // Cubic cells of about `target_cells` over the core range qs (exact bbox kept in gmin/gmax for certification).
 template <typename T>
 __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, const QuantState<T>* qs, double target_cells,
-                                  int max_cells, Pt4<T>* sentinel, int closed, const double* target_dev) {
+                                  int max_cells, Pt4<T>* sentinel, int n_sorted, int closed, const double* target_dev) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (target_dev) target_cells = *target_dev;
-    if (sentinel) for (int j = 0; j < 8; ++j) { sentinel[j].x = sentinel[j].y = sentinel[j].z = (T)INFINITY; sentinel[j].idx = 0x7fffffff; }
+    if (sentinel) put_sentinels(sentinel - n_sorted, n_sorted);
     double ext[3];
     for (int j = 0; j < 3; ++j) { gp->gmin[j] = base->gmin[j]; gp->gmax[j] = base->gmax[j]; gp->org[j] = qs->lo[j]; ext[j] = (double)qs->hi[j] - (double)qs->lo[j]; }
     double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);

@@ -131,7 +131,13 @@ __global__ void k_kd_root(KdBuild<T> b, const GridParams<T>* gp, int n) {
     if (threadIdx.x || blockIdx.x) return;
     KdNode<T>& nd = b.nodes[0];
     kd_node_init(nd, 0, n);
-    for (int j = 0; j < 3; ++j) { nd.bb_lo[j] = gp->gmin[j]; nd.bb_hi[j] = gp->gmax[j]; }
+    // nanoflann's computeBoundingBox (nanoflann.hpp:1513-1541) runs over ALL points; the grid's box is that of the finite ones, and the raw
+    // non-finite mask (grid.h: bits 1..3 = +inf, 4..6 = -inf on axis j) says where an infinity widens it (NaN never gets here: rejected)
+    const unsigned raw = (unsigned)gp->nonfinite >> 8;
+    for (int j = 0; j < 3; ++j) {
+        nd.bb_lo[j] = (raw >> (4 + j)) & 1u ? -(T)INFINITY : gp->gmin[j];
+        nd.bb_hi[j] = (raw >> (1 + j)) & 1u ? (T)INFINITY : gp->gmax[j];
+    }
     *b.n_nodes = 1; *b.n_real = 1; *b.n_next = 0; *b.n_sub = 0; *b.max_depth = 0;
     if (n <= b.sub_max) { b.sub_nodes[0] = 0; *b.n_sub = 1; *b.n_items = 0; *b.n_cur = 0; }
     else { *b.n_cur = 1; b.level_nodes[0] = 0; b.level_cbase[0] = 0; b.level_cbase[1] = (n + kKdChunk - 1) / kKdChunk; *b.n_items = b.level_cbase[1]; }

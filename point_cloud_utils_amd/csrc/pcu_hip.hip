@@ -225,7 +225,7 @@ static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
 template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
-    size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8) * 4, 256) + align_up((size_t)(n + 8) * sizeof(Pt4<T>), 256) +
+    size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8) * 4, 256) + align_up(sorted_records_bytes((size_t)n, sizeof(Pt4<T>), sizeof(T)), 256) +
                2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * kBboxStride * sizeof(T), 256);
     int sh = 0, nb = 0;
     if (bucket_plan(n, occ, &sh, &nb))
@@ -239,7 +239,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
     g.bucketed = allow_bucketed && bucket_plan(n, occ, &g.shift, &g.nb_max);
     if (aalloc(a, &g.gp, 1)) return -1;
     if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1 + kBkMaxBuckets + 8)) return -1;    // + bucket totals + large-bucket count (zeroed together)
-    if (aalloc(a, &g.sorted, (size_t)n + 8)) return -1;        // + the +inf sentinel records
+    if (a.alloc((void**)&g.sorted, sorted_records_bytes((size_t)n, sizeof(Pt4<T>), sizeof(T)))) return -1;        // + the +inf sentinel records + the coordinates-only copy (pcu_types.h: xyz_of)
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
     if (aalloc(a, &g.block_sums, (size_t)g.scan_blocks + 1)) return -1;
@@ -259,7 +259,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
 }
 // Placement of the records of over-full buckets (grid.h): one launch for up to two indexes built back to back.
 template <typename T>
-static LargeJob<T> large_job(const GridIndex<T>& g) { return LargeJob<T>{g.gp, g.bucket_start, g.large_list, g.n_large, g.tmp, g.rank, g.cell_start, g.sorted, g.pos_of}; }
+static LargeJob<T> large_job(const GridIndex<T>& g) { return LargeJob<T>{g.gp, g.bucket_start, g.large_list, g.n_large, g.tmp, g.rank, g.cell_start, g.sorted, g.pos_of, g.n}; }
 template <typename T>
 static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipStream_t s) {
     const bool ua = a.bucketed, ub = b && b->bucketed;
@@ -285,15 +285,17 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     if (b) { b->src = pb; b->occ_built = occb; }
     // one launch set serves both clouds only if they are built the same way
     if (b && a.bucketed && b->bucketed && a.one_pass != b->one_pass) a.one_pass = b->one_pass = false;
+    const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n, a.h_want, pa};
+    const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n, b->h_want, pb} : g0;
+    // When every cloud of the call takes the one-pass bucket build, its blocks lay out the grid themselves (grid.h: k_bucket_onepass)
+    // and the k_make_grid launch is skipped. (bbox + grid layout in ONE launch, the last block folding the partials, was measured in
+    // round 2: 16.7 us against 8.1 + 4.9 us for the two launches; removed.)
+    const bool grid_in_onepass = a.bucketed && a.one_pass && (!b || (b->bucketed && b->one_pass));
     {
-        const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2};
-        const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0} : s0;
-        const GridSide<T> g0{a.gp, a.bbox_partial, kBboxBlocks, a.n, occa, a.max_cells, a.sorted + a.n, a.h_want};
-        const GridSide<T> g1 = b ? GridSide<T>{b->gp, b->bbox_partial, kBboxBlocks, b->n, occb, b->max_cells, b->sorted + b->n, b->h_want} : g0;
-        // (bbox + grid layout in ONE launch -- the last block folding the partials -- was measured in round 2: 16.7 us against
-        // 8.1 + 4.9 us for the two launches; removed)
+        const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2, a.gp};
+        const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0, b->gp} : s0;
         hipLaunchKernelGGL(k_bbox_partial<T>, dim3(b ? 2 * kBboxBlocks : kBboxBlocks), dim3(kBlock), 0, s, s0, s1, kBboxBlocks);
-        hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
+        if (!grid_in_onepass) hipLaunchKernelGGL(k_make_grid<T>, dim3(b ? 2 : 1), dim3(kBlock), 0, s, g0, g1);
     }
     // bucketed sides share their launches; a side too small / too coarse for buckets takes the atomic passes
     const GridIndex<T>* bs[2]; const T* bp[2]; int nbs = 0;
@@ -311,7 +313,9 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             static long long* prof1 = nullptr;
             if (do_prof && !prof1) HIP_TRY(hipMalloc((void**)&prof1, 8 * sizeof(long long)));
             if (do_prof) HIP_TRY(hipMemsetAsync(prof1, 0, 8 * sizeof(long long), s));
-            hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0, do_prof ? prof1 : nullptr);
+            // (the grid sides in the order of the bucket sides: both clouds are bucketed whenever two are built this way)
+            hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0, do_prof ? prof1 : nullptr,
+                               bs[0] == &a ? g0 : g1, nbs > 1 ? g1 : (bs[0] == &a ? g0 : g1));
             if (do_prof) {
                 long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof1, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
                 const double nb = h[7] > 0 ? (double)h[7] : 1.0;
@@ -386,7 +390,7 @@ static int index_build_refit(Arena& ar, GridIndex<T>& g, const GridIndex<T>& bas
     if (target_cells < 1.0) target_cells = 1.0;
     if (index_alloc(ar, g, n, (double)n / target_cells, false, /*allow_bucketed=*/false)) return -1;
     const int nb = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n,
+    hipLaunchKernelGGL(k_make_grid_refit<T>, dim3(1), dim3(64), 0, s, g.gp, base.gp, qs, target_cells, g.max_cells, g.sorted + n, n,
                        closed ? 1 : 0, target_dev);
     HIP_TRY(hipMemsetAsync(g.cell_start, 0, ((size_t)g.max_cells + 1) * 4, s));
     hipLaunchKernelGGL(k_count<T>, dim3(nb), dim3(kBlock), 0, s, d_pts, n, g.gp, g.cell_of, g.rank, g.cell_start);
@@ -441,6 +445,10 @@ constexpr int kWaveBlocks = PCU_WAVE_BLOCKS;    // fixed grid of the wave-cooper
 
 // whole-call index builds use the one-pass bucket scatter until a cloud of this context overflows a slot (PCU_HIP_TWO_PASS=1: never)
 static bool use_one_pass(const pcu_hip_ctx* c) { static const bool off = getenv("PCU_HIP_TWO_PASS") != nullptr; return !off && !c->two_pass; }
+// The wave-per-query launch of a call finishes its stragglers itself (search.h: k_search_wave, box round -> ball round); PCU_HIP_NO_ESCALATE=1
+// leaves them to the host-driven passes of search_finish (radius 4 ... 16, then coarser grids), the pre-round-3 behaviour and still the
+// path of closed sub-box levels.
+static int wave_escalates() { static const bool off = getenv("PCU_HIP_NO_ESCALATE") != nullptr; return off ? 0 : 1; }
 static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }
 static int grid8(int nwork, int tb) { return (((nwork + tb - 1) / tb) + 7) / 8 * 8; }       // multiple of 8: XCD-aware block map
 
@@ -540,6 +548,7 @@ template <typename T>
 static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) {
     SearchArgs<T> a;
     a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted; a.n_ref = (unsigned)ridx.n;
+    a.ref_xyz = xyz_of(ridx.sorted, ridx.n);
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
     a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0; a.row_out = j.row_out ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
@@ -552,7 +561,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.lane_max_cand = j.n_fine > 0 ? (unsigned)std::max(384.0, 6.0 * 27.0 * j.occ) : (unsigned)std::max(4096.0, 64.0 * 27.0 * j.occ);
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
-    a.bad_r = j.bad_r; a.bad_q = j.bad_q;
+    a.bad_r = j.bad_r; a.bad_q = j.bad_q; a.escalate = 0;
     return a;
 }
 
@@ -591,6 +600,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
         b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
+        b.escalate = wave_escalates();                                           // ... and whatever it takes after that, inside the launch
         if (launch_search_wave<T>(KL, b, s)) return -1;
         if (st) st->n_passes += 2 + j.n_fine;
     } else {
@@ -602,6 +612,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         b.nq = 0; b.skew_limit = 0.f; b.skew_lo = 0.f;
         b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;             // stragglers, radius 2
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
+        b.escalate = wave_escalates();
         if (launch_search_wave<T>(KL, b, s)) return -1;
         if (st) st->n_passes += 2;
     }
@@ -634,6 +645,7 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
         b[d].qlist = sc.t1; b[d].qcount_dev = sc.counters + C_T1; b[d].R = 1;            // possible ties -> total order, radius 1
         b[d].qlist2 = sc.u1; b[d].qcount2_dev = sc.counters + C_U1; b[d].R2 = 2;         // stragglers, radius 2
         b[d].unresolved = sc.u2; b[d].n_unresolved = sc.counters + C_U2;
+        b[d].escalate = wave_escalates();
     }
     const bool time_it = st && c->time_kernels && c->n_kev + 2 <= 8;
     if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);

@@ -34,6 +34,7 @@ template <typename T>
 struct SearchArgs {
     const GridParams<T>* gp;        // dataset grid
     const Pt4<T>* ref;              // dataset in cell order
+    const T* ref_xyz;               // the same records without the row id (3 T each; GridIndex::xyz), k_search1_flat's candidate stream
     const unsigned* cell_start;     // [ncells+1]
     const Pt4<T>* qsorted;          // queries in their own cell order
     const int* qlist;               // nullable: positions into qsorted to process (escalation / tie passes)
@@ -72,6 +73,7 @@ struct SearchArgs {
     unsigned long long* f_limbs; double* f_special; T* f_wave_v; long long* f_wave_k;
     int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
                                     // slots instead of overwriting them
+    int escalate;                   // wave-per-query passes: finish every query inside the launch (box round, then the ball round: k_search_wave)
     int bad_r, bad_q;               // GridParams::nonfinite flags (grid.h: kNf*) of the dataset / of the query cloud that this operator rejects:
                                     // the passes give up at once and raise bit 2 of the large-bucket flag word (-> ValueError on the host)
 };
@@ -404,37 +406,95 @@ __device__ __forceinline__ unsigned lb_pack(float lb) { return __float_as_uint(l
 __device__ __forceinline__ unsigned lb_pack(double lb) { const double v = lb * (1.0 - 1e-6); return __float_as_uint((float)(v < 1e38 ? v : 1e38)) >> 16; }
 template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { return (T)__uint_as_float(b << 16); }
 
+// Variants of the k = 1 main pass (compile-time, A/B-measured on the GPU; profiles/r03_*):
+//   PCU_FLAT_XYZ   candidates are read from a coordinates-only copy of the cell-ordered cloud (GridIndex::xyz: 3 T per record, no
+//                  row id): a group of 4 records is 12 consecutive scalars = THREE 16-byte loads instead of four, and the six
+//                  (x,y) / (z,x) / (y,z) pairs of the group go through the packed-fp32 pipe. A per-lane gather instruction costs
+//                  the CU's L1 / texture-address path ~17-21 cycles whatever its width (profiles/r02_ubench.txt), and that path is
+//                  the kernel's tightest resource, so a quarter fewer instructions in the loops is a quarter less of it. The row id
+//                  of the winner is fetched once, at the end, from the Pt4 records (not at all by the fused Chamfer sum).
+// Measured and rejected in round 3 (profiles/r03_flat_ab.txt): re-dealing the block's 256 queries to its lanes by remaining work after
+// the centre row (LDS counting sort + hand-over of the query state, wave 0 = the 64 heaviest ...): fewer loop trips, but four block
+// barriers in a latency-bound kernel, 80 instead of 72 VGPRs and 25 KB of LDS: 85.9 vs 83.9 us alone, 81.0 vs 78.0 us on top of XYZ.
+#ifndef PCU_FLAT_XYZ
+#define PCU_FLAT_XYZ 1
+#endif
+constexpr bool kFlatXyz = PCU_FLAT_XYZ != 0;
+
+template <typename T> struct __attribute__((packed, aligned(4))) Group12 { T v[12]; };      // 4 records of a coordinates-only stream
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One group = 4 consecutive records of the candidate stream: `load` requests it (straight-line loads), `dists` gives the 4 squared
+// distances (bit-identical to 4 x dist2: IEEE subtract, multiply, add in the reference's order).
+template <typename T, bool XYZ> struct GroupEval;
+template <typename T> struct GroupEval<T, false> {           // Pt4 records
+    static constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
+    struct Raw { Pt4<T> c[4]; };
+    static __device__ __forceinline__ Raw load(const char* base, unsigned off) {
+        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
+        Raw r; r.c[0] = c[0]; r.c[1] = c[1]; r.c[2] = c[2]; r.c[3] = c[3]; return r;
+    }
+    static __device__ __forceinline__ void dists(const Raw& r, const Pt4<T>& q, T (&d)[4]) {
+        d[0] = dist2_k1(q, r.c[0]); d[1] = dist2_k1(q, r.c[1]); d[2] = dist2_k1(q, r.c[2]); d[3] = dist2_k1(q, r.c[3]);
+    }
+};
+template <> struct GroupEval<float, true> {
+    static constexpr unsigned kRec = 12u;
+    typedef Group12<float> Raw;
+    static __device__ __forceinline__ Raw load(const char* base, unsigned off) { return *reinterpret_cast<const Raw*>(base + (size_t)off); }
+    static __device__ __forceinline__ void dists(const Raw& g, const Pt4<float>& q, float (&d)[4]) {
+        const f32x2 qxy = {q.x, q.y}, qzx = {q.z, q.x}, qyz = {q.y, q.z};
+        f32x2 p0 = qxy - f32x2{g.v[0], g.v[1]}, p1 = qzx - f32x2{g.v[2], g.v[3]}, p2 = qyz - f32x2{g.v[4], g.v[5]};
+        f32x2 p3 = qxy - f32x2{g.v[6], g.v[7]}, p4 = qzx - f32x2{g.v[8], g.v[9]}, p5 = qyz - f32x2{g.v[10], g.v[11]};
+        p0 = p0 * p0; p1 = p1 * p1; p2 = p2 * p2; p3 = p3 * p3; p4 = p4 * p4; p5 = p5 * p5;
+        d[0] = (p0.x + p0.y) + p1.x; d[1] = (p1.y + p2.x) + p2.y; d[2] = (p3.x + p3.y) + p4.x; d[3] = (p4.y + p5.x) + p5.y;
+    }
+};
+template <> struct GroupEval<double, true> {
+    static constexpr unsigned kRec = 24u;
+    typedef Group12<double> Raw;
+    static __device__ __forceinline__ Raw load(const char* base, unsigned off) { return *reinterpret_cast<const Raw*>(base + (size_t)off); }
+    static __device__ __forceinline__ void dists(const Raw& g, const Pt4<double>& q, double (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double dx = q.x - g.v[3 * u], dy = q.y - g.v[3 * u + 1], dz = q.z - g.v[3 * u + 2]; d[u] = ((dx * dx) + (dy * dy)) + (dz * dz); }
+    }
+};
 // Register layout: the centre row's table is loaded and scanned first; only then are the other eight rows' tables fetched
 // (EARLY = false: one more dependent wait per wave, but their 32 registers are not live during the centre scan: 68 VGPRs
 // instead of 93, 7 waves per SIMD instead of 5). EARLY = true fetches them right away (79 VGPRs; measured equal).
 template <typename T, bool EARLY, int FUSE>
 __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const int nq_arg, const int bid, const int nblk, bool& f_ok, T& f_v, long long& f_key) {
+    constexpr bool XYZ = kFlatXyz;
+    typedef GroupEval<T, XYZ> GE;
     __shared__ uint2 s_rng[8][kBlock];
     const int per = nblk >> 3;
     const int vb = (bid & 7) * per + (bid >> 3);       // XCD-aware block order, see k_search (nblk and the side's first block: multiples of 8)
-    const int t = vb * kBlock + threadIdx.x;
-    const int nq = a.qcount_dev ? *a.qcount_dev : nq_arg;
-    if (t >= nq) return;
     const int tid = threadIdx.x;
+    const int nq = a.qcount_dev ? *a.qcount_dev : nq_arg;
+    if (vb * kBlock >= nq) return;                     // (block-uniform)
+    const GridParams<T>& g = *a.gp;
+    if (const int hl = index_not_ready(a, g)) { if (vb == 0 && tid == 0) a.skew_flag[kLargeFlag] = hl; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (vb == 0 && tid == 0) *a.skew_flag = 1; return; }
+    const int t = vb * kBlock + tid;
+    if (t >= nq) return;
+    constexpr bool valid = true;
     const int qpos = a.qlist ? a.qlist[t] : t;
     const Pt4<T> q = a.qsorted[qpos];
-    const GridParams<T>& g = *a.gp;
-    if (const int hl = index_not_ready(a, g)) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
-    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
     const int len = x1 - x0 + 1;                      // cells per row run: 3, 2 at a grid border (1 if Gx == 1)
-    constexpr unsigned kRec = (unsigned)sizeof(Pt4<T>);
+    constexpr unsigned kRec = GE::kRec;               // bytes per record of the candidate stream
     constexpr int kG = K1Group<T>::n;
-    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const char* const base = XYZ ? reinterpret_cast<const char*>(a.ref_xyz) : reinterpret_cast<const char*>(a.ref);
     const unsigned cand_cap = a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u;     // a run's record count is packed into 16 bits
     T best = Limits<T>::max_v;
     unsigned boff = 0xffffffffu, toff = 0xffffffffu;
     bool tie = false, tie2 = false;
-#define PCU_K1_EVAL(C0, C1, C2, C3, OFF)                                                                     \
+#define PCU_K1_EVAL(RAW, OFF)                                                                                \
     {                                                                                                        \
-        const T m_ = min4(dist2_k1(q, C0), dist2_k1(q, C1), dist2_k1(q, C2), dist2_k1(q, C3));             \
+        T d_[4]; GE::dists((RAW), q, d_);                                                                    \
+        const T m_ = min4(d_[0], d_[1], d_[2], d_[3]);                                                       \
         const bool eq_ = m_ == best, lt_ = m_ < best;                                                        \
         tie2 = !lt_ && (tie2 || (tie && eq_));                                                               \
         tie = !lt_ && (tie || eq_);                                                                          \
@@ -445,9 +505,11 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     auto row_table = [&](int j, bool& ok, bool& odd) {
         const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
         ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
-        const int row = grid_row(Gy, ok ? cy : ccy, ok ? cz : ccz);
-        odd = row & 1;
-        return *reinterpret_cast<const CellStart4*>(a.cell_start + row_run_lo(Gx, row, x0, x1));
+        // rows < 2^22, cells per row <= 2048, cells < 2^26: a 24-bit multiply (full rate) and a 32-bit byte offset from the uniform base
+        const unsigned row = (unsigned)(ok ? cz : ccz) * (unsigned)Gy + (unsigned)(((ok ? cz : ccz) & 1) ? Gy - 1 - (ok ? cy : ccy) : (ok ? cy : ccy));
+        odd = row & 1u;
+        const unsigned lo = __umul24(row, (unsigned)Gx) + (unsigned)(odd ? Gx - 1 - x1 : x0);
+        return *reinterpret_cast<const CellStart4*>(reinterpret_cast<const char*>(a.cell_start) + (size_t)(lo * 4u));
     };
     bool okj[9], oddj[9];
     CellStart4 tb[9];
@@ -461,12 +523,8 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     bool defer = cnt0 > cand_cap;
     {
         const unsigned o0 = tb[0].v[0] * kRec;
-        const unsigned o1 = defer ? o0 : o0 + cnt0 * kRec;
-        for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) {
-            const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off);
-            const Pt4<T> c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-            PCU_K1_EVAL(c0, c1, c2, c3, off)
-        }
+        const unsigned o1 = (defer || !valid) ? o0 : o0 + cnt0 * kRec;
+        for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) { const typename GE::Raw raw = GE::load(base, off); PCU_K1_EVAL(raw, off) }
     }
     // ---- the other rows: cut runs that survive the centre row's minimum -> this lane's list
     if (!EARLY) {
@@ -502,42 +560,42 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         const unsigned e_full = len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1]);
         const unsigned e_cut = len == 3 ? tb[j].v[2] : (len == 2 ? tb[j].v[1] : tb[j].v[0]);
         const unsigned e_run = cut_last ? e_cut : e_full;
-        if (okj[j] && !defer && !(best < rlb) && e_run > s_run) {
+        if (valid && okj[j] && !defer && !(best < rlb) && e_run > s_run) {
             s_rng[n][tid] = make_uint2(s_run * kRec, ((e_run - s_run) << 16) | lb_pack(rlb));
             ++n;
         }
     }
+    const int own = tid;
     int r = 0;
     unsigned off = 0, end = 0;
     bool live = false;
     auto next_run = [&]() {
         live = false;
         while (r < n) {
-            const uint2 e = s_rng[r][tid];
+            const uint2 e = s_rng[r][own];
             ++r;
             if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + (e.y >> 16) * kRec; live = true; break; }
         }
     };
     next_run();
-    // Ping-pong: A is evaluated while B's four loads are in flight, and vice versa. The loads are unconditional
-    // straight-line code (a lane that has just run out of work fetches the +inf sentinel records once): loads issued under
-    // a branch would make the compiler wait for them at the join, i.e. before the older group is evaluated.
+    // Ping-pong: A is evaluated while B's loads are in flight, and vice versa. The loads are unconditional straight-line code (a lane
+    // that has just run out of work fetches the +inf sentinel records once): loads issued under a branch would make the compiler wait
+    // for them at the join, i.e. before the older group is evaluated.
     const unsigned sent_off = a.n_ref * kRec;
     if (live) {
-        Pt4<T> a0, a1, a2, a3, b0, b1, b2, b3;
-        { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)off); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
+        typename GE::Raw ga = GE::load(base, off), gb;
         for (;;) {
             unsigned coff = off;
             off += (unsigned)kG * kRec;
             if (off >= end) next_run();
-            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); b0 = c[0]; b1 = c[1]; b2 = c[2]; b3 = c[3]; }
-            PCU_K1_EVAL(a0, a1, a2, a3, coff)
+            gb = GE::load(base, live ? off : sent_off);
+            PCU_K1_EVAL(ga, coff)
             if (!live) break;
             coff = off;
             off += (unsigned)kG * kRec;
             if (off >= end) next_run();
-            { const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)(live ? off : sent_off)); a0 = c[0]; a1 = c[1]; a2 = c[2]; a3 = c[3]; }
-            PCU_K1_EVAL(b0, b1, b2, b3, coff)
+            ga = GE::load(base, live ? off : sent_off);
+            PCU_K1_EVAL(gb, coff)
             if (!live) break;
         }
     }
@@ -545,41 +603,38 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     // ---- which record of the winning group it was; ties (see k_search1)
     T bd[1] = {best};
     int bi[1] = {0x7fffffff};
-    if (boff != 0xffffffffu) {
-        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)boff);
-        int hits = 0;
+    auto which = [&](unsigned goff, int& hits, unsigned& rec_off) {         // records of the group at `goff` whose d2 equals the minimum
+        T d_[4]; GE::dists(GE::load(base, goff), q, d_);
+        hits = 0; rec_off = 0xffffffffu;
 #pragma unroll
-        for (int u = kG - 1; u >= 0; --u) {
-            const Pt4<T> cu = c[u];
-            const bool eq = dist2_k1(q, cu) == best;
-            hits += eq ? 1 : 0;
-            bi[0] = eq ? (int)cu.idx : bi[0];
-        }
+        for (int u = kG - 1; u >= 0; --u) { const bool eq = d_[u] == best; hits += eq ? 1 : 0; rec_off = eq ? goff + (unsigned)u * kRec : rec_off; }
+    };
+    auto row_id = [&](unsigned rec_off) -> int {
+        if (!XYZ) return (int)reinterpret_cast<const Pt4<T>*>(base + (size_t)rec_off)->idx;
+        return (int)a.ref[rec_off / kRec].idx;
+    };
+    if (FUSE != FUSE_SUM && boff != 0xffffffffu) {        // (a fused sum needs neither the row id nor the tie flags)
+        int hits; unsigned ro;
+        which(boff, hits, ro);
+        if (ro != 0xffffffffu) bi[0] = row_id(ro);
         if (hits > 1) { tie = true; tie2 = true; }
-    }
-    if (tie && !tie2) {
-        const Pt4<T>* c = reinterpret_cast<const Pt4<T>*>(base + (size_t)toff);
-        int hits = 0, id = 0x7fffffff;
-#pragma unroll
-        for (int u = kG - 1; u >= 0; --u) {
-            const Pt4<T> cu = c[u];
-            const bool eq = dist2_k1(q, cu) == best;
-            hits += eq ? 1 : 0;
-            id = eq ? (int)cu.idx : id;
+        if (tie && !tie2) {
+            int h2; unsigned ro2;
+            which(toff, h2, ro2);
+            if (h2 == 1 && ro2 == ro) tie = false;        // the same record met twice (groups run past their run's end)
         }
-        if (hits == 1 && id == bi[0]) tie = false;
     }
     const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
     const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, true, defer); return; }
+    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, valid, defer); return; }
     // fused epilogue: the lane's distance goes into the block's partial (kernel wrapper) instead of a result row
     if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
-        wave_append(true, qpos, a.ties, a.n_ties);
+        wave_append(valid, qpos, a.ties, a.n_ties);
         return;
     }
     const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
-    const bool certified = best < lb;
-    wave_append(!certified, qpos, a.unresolved, a.n_unresolved);
+    const bool certified = valid && best < lb;
+    wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
     f_ok = certified;
     f_v = a.squared ? best : sqrt(best);
     f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
@@ -654,18 +709,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
         const int kreq = a.kreq;
         const bool second = w >= nq1;
-        const int R = second ? a.R2 : a.R;
+        int R = second ? a.R2 : a.R;
         const int qpos = second ? a.qlist2[w - nq1] : (a.qlist ? a.qlist[w] : w);
         const Pt4<T> q = a.qsorted[qpos];
         const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
-        const int x0 = max(ccx - R, 0), x1 = min(ccx + R, Gx - 1);
-        const int y0 = max(ccy - R, 0), y1 = min(ccy + R, Gy - 1);
-        const int z0 = max(ccz - R, 0), z1 = min(ccz + R, Gz - 1);
-        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        const T shrink = (T)1 - (T)4 * Limits<T>::eps;
 
         T bd[K]; int bi[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
         // one candidate into this lane's K best under the total order (d2, dataset row)
         auto take = [&](const T d, const int id) {
             if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
@@ -680,72 +730,122 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             }
         };
         constexpr unsigned kHeavyRow = 256;        // a row with more candidates than this is scanned by the whole wave
-        // (2R+1)^2 <= 32 rows (radius 1 and 2, i.e. nearly every query that gets here): two lanes per row, each takes half of it --
-        // the pass is a chain of dependent loads per lane, so halving the chain halves the query
-        const int sp = nrows <= 32 ? 2 : 1;
-        for (int r0 = 0; r0 < nrows; r0 += 64 / sp) {
-            const int r = r0 + (sp == 2 ? lane >> 1 : lane);
-            unsigned s = 0, e = 0;
-            if (r < nrows) {
-                const int cz = z0 + r / ny, cy = y0 + r % ny;
-                const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), x0, x1);
-                s = a.cell_start[lo]; e = a.cell_start[lo + (x1 - x0 + 1)];
+        T my_d, my_d2, kth; int my_i, my_i2; bool tie, certified;
+        // A query is served in up to a few rounds, all inside this launch (SearchArgs::escalate; without it one round, and what is
+        // left uncertified goes to the `unresolved` list for the host-driven passes):
+        //   box round   the (2R+1)^3 cells around the query's cell, certified by face_lower_bound as in the lane passes;
+        //   ball round  if the box round found k points but could not certify them, its k-th best d2 = B bounds the true one, and
+        //               every point that can still matter lies in the ball of radius sqrt(B): the rows (cy, cz) whose slab is within
+        //               B of the query, and of each such row the cells within sqrt(B - row bound) along x (+-1 cell of margin; the
+        //               bounds are the rounding-safe ones of the row pruning, strict '>': no tie can hide in what is skipped).
+        //               Whatever the round returns is final by construction -- however far the query is from its neighbours, and
+        //               without coarser grids or a host round trip per radius;
+        //   wider box   if the box held fewer than k points, its radius grows four-fold (up to the whole grid).
+        T ball = Limits<T>::max_v;                  // < max_v: ball round with this bound
+        const bool esc = a.escalate && !g.closed;   // (a closed sub-box level does not hold the points beyond its box: nothing to finish there)
+        for (int round = 0;; ++round) {
+            const bool is_ball = ball < Limits<T>::max_v;
+            int x0, x1, y0, y1, z0, z1;
+            if (!is_ball) {
+                x0 = max(ccx - R, 0); x1 = min(ccx + R, Gx - 1);
+                y0 = max(ccy - R, 0); y1 = min(ccy + R, Gy - 1);
+                z0 = max(ccz - R, 0); z1 = min(ccz + R, Gz - 1);
+            } else {
+                const T rr = sqrt(ball) * ((T)1 + (T)8 * Limits<T>::eps);
+                x0 = 0; x1 = Gx - 1;                // (per row, below)
+                y0 = max(grid_cell(g, 1, q.y - rr) - 1, 0); y1 = min(grid_cell(g, 1, q.y + rr) + 1, Gy - 1);
+                z0 = max(grid_cell(g, 2, q.z - rr) - 1, 0); z1 = min(grid_cell(g, 2, q.z + rr) + 1, Gz - 1);
             }
-            const bool heavy = e - s > kHeavyRow;
-            unsigned ls = s, le = e;                // this lane's share of the row
-            if (sp == 2) { const unsigned mid = s + ((e - s + 1u) >> 1); if (lane & 1) ls = mid; else le = mid; }
-            // light rows. K <= 32: four candidates per trip, their loads issued together (the pass is
-            // latency-bound); slots past the share's end are killed (+inf / NaN d2 never enters the list)
-            constexpr int kU = K <= 32 ? 4 : 1;            // (K = 64, 128: the lists fill the register file)
-            for (unsigned p = ls; p < (heavy ? ls : le); p += kU) {
-                Pt4<T> cc[kU];
+            const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
 #pragma unroll
-                for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, le - 1u)];
+            for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
+            // (2R+1)^2 <= 32 rows (radius 1 and 2, i.e. nearly every query that gets here): two lanes per row, each takes half of it --
+            // the pass is a chain of dependent loads per lane, so halving the chain halves the query
+            const int sp = nrows <= 32 ? 2 : 1;
+            for (int r0 = 0; r0 < nrows; r0 += 64 / sp) {
+                const int r = r0 + (sp == 2 ? lane >> 1 : lane);
+                unsigned s = 0, e = 0;
+                if (r < nrows) {
+                    const int cz = z0 + r / ny, cy = y0 + r % ny;
+                    int xa = x0, xb = x1;
+                    bool on = true;
+                    if (is_ball) {
+                        // distance from the query to the slab of this row (0: the query's own), as in row_lower_bounds
+                        T my = (T)0, mz = (T)0;
+                        if (cy < ccy) { const T m = q.y - face_below(g, 1, cy + 1); my = m > (T)0 ? m * shrink : (T)0; }
+                        if (cy > ccy) { const T m = face_above(g, 1, cy - 1) - q.y; my = m > (T)0 ? m * shrink : (T)0; }
+                        if (cz < ccz) { const T m = q.z - face_below(g, 2, cz + 1); mz = m > (T)0 ? m * shrink : (T)0; }
+                        if (cz > ccz) { const T m = face_above(g, 2, cz - 1) - q.z; mz = m > (T)0 ? m * shrink : (T)0; }
+                        const T rlb = (my * my) + (mz * mz);
+                        on = !(ball < rlb);
+                        const T rx2 = ball * ((T)1 + (T)8 * Limits<T>::eps) - rlb;
+                        const T rx = (rx2 > (T)0 ? sqrt(rx2) : (T)0) * ((T)1 + (T)8 * Limits<T>::eps);
+                        xa = max(grid_cell(g, 0, q.x - rx) - 1, 0); xb = min(grid_cell(g, 0, q.x + rx) + 1, Gx - 1);
+                    }
+                    if (on) {
+                        const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), xa, xb);
+                        s = a.cell_start[lo]; e = a.cell_start[lo + (xb - xa + 1)];
+                    }
+                }
+                const bool heavy = e - s > kHeavyRow;
+                unsigned ls = s, le = e;                // this lane's share of the row
+                if (sp == 2) { const unsigned mid = s + ((e - s + 1u) >> 1); if (lane & 1) ls = mid; else le = mid; }
+                // light rows. K <= 32: four candidates per trip, their loads issued together (the pass is
+                // latency-bound); slots past the share's end are killed (+inf / NaN d2 never enters the list)
+                constexpr int kU = K <= 32 ? 4 : 1;            // (K = 64, 128: the lists fill the register file)
+                for (unsigned p = ls; p < (heavy ? ls : le); p += kU) {
+                    Pt4<T> cc[kU];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const Pt4<T>& c = cc[u];
-                    const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                    take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= le), (int)c.idx);
+                    for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, le - 1u)];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const Pt4<T>& c = cc[u];
+                        const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                        take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= le), (int)c.idx);
+                    }
+                }
+                // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
+                // lane keeps the best of its share, the rounds below merge the lanes' lists as for light rows
+                unsigned long long hm = __ballot(heavy && (sp == 1 || !(lane & 1)));        // (once per row)
+                while (hm) {
+                    const int owner = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1;
+                    const unsigned hs = (unsigned)__shfl((int)s, owner, 64), he = (unsigned)__shfl((int)e, owner, 64);
+                    for (unsigned p = hs + (unsigned)lane; p < he; p += 64u) {
+                        const Pt4<T> c = a.ref[p];
+                        const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                        take(((dx * dx) + (dy * dy)) + (dz * dz), (int)c.idx);
+                    }
                 }
             }
-            // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
-            // lane keeps the best of its share, the rounds below merge the lanes' lists as for light rows
-            unsigned long long hm = __ballot(heavy && (sp == 1 || !(lane & 1)));        // (once per row)
-            while (hm) {
-                const int owner = __ffsll((long long)hm) - 1;
-                hm &= hm - 1;
-                const unsigned hs = (unsigned)__shfl((int)s, owner, 64), he = (unsigned)__shfl((int)e, owner, 64);
-                for (unsigned p = hs + (unsigned)lane; p < he; p += 64u) {
-                    const Pt4<T> c = a.ref[p];
-                    const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                    take(((dx * dx) + (dy * dy)) + (dz * dz), (int)c.idx);
-                }
-            }
-        }
-        // K rounds: global lexicographic minimum of the lanes' heads; the owner pops.
-        T my_d = Limits<T>::max_v; int my_i = 0x7fffffff;    // lane j keeps rank j ...
-        T my_d2 = Limits<T>::max_v; int my_i2 = 0x7fffffff;  // ... and rank j + 64 (K = 128)
-        T prev_d = (T)-1; T kth = Limits<T>::max_v; bool tie = false;
+            // K rounds: global lexicographic minimum of the lanes' heads; the owner pops.
+            my_d = Limits<T>::max_v; my_i = 0x7fffffff;     // lane j keeps rank j ...
+            my_d2 = Limits<T>::max_v; my_i2 = 0x7fffffff;   // ... and rank j + 64 (K = 128)
+            T prev_d = (T)-1; kth = Limits<T>::max_v; tie = false;
 #pragma unroll 1
-        for (int j = 0; j < K; ++j) {
-            T md = bd[0]; int mi = bi[0];
+            for (int j = 0; j < K; ++j) {
+                T md = bd[0]; int mi = bi[0];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const T od = __shfl_xor(md, o, 64); const int oi = __shfl_xor(mi, o, 64);
-                if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
-            }
-            if (bi[0] == mi && bd[0] == md && mi != 0x7fffffff) {          // owner (dataset rows are unique)
+                for (int o = 32; o > 0; o >>= 1) {
+                    const T od = __shfl_xor(md, o, 64); const int oi = __shfl_xor(mi, o, 64);
+                    if (lex_less(od, oi, md, mi)) { md = od; mi = oi; }
+                }
+                if (bi[0] == mi && bd[0] == md && mi != 0x7fffffff) {          // owner (dataset rows are unique)
 #pragma unroll
-                for (int i = 0; i < K - 1; ++i) { bd[i] = bd[i + 1]; bi[i] = bi[i + 1]; }
-                bd[K - 1] = Limits<T>::max_v; bi[K - 1] = 0x7fffffff;
+                    for (int i = 0; i < K - 1; ++i) { bd[i] = bd[i + 1]; bi[i] = bi[i + 1]; }
+                    bd[K - 1] = Limits<T>::max_v; bi[K - 1] = 0x7fffffff;
+                }
+                if (lane == (j & 63)) { if (j < 64) { my_d = md; my_i = mi; } else { my_d2 = md; my_i2 = mi; } }
+                if (j <= kreq && mi != 0x7fffffff && md == prev_d) tie = true;
+                if (j == kreq - 1) kth = md;
+                prev_d = md;
             }
-            if (lane == (j & 63)) { if (j < 64) { my_d = md; my_i = mi; } else { my_d2 = md; my_i2 = mi; } }
-            if (j <= kreq && mi != 0x7fffffff && md == prev_d) tie = true;
-            if (j == kreq - 1) kth = md;
-            prev_d = md;
+            certified = is_ball || kth < face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+            if (certified || !esc) break;
+            if (kth < Limits<T>::max_v) ball = kth;                // k points seen: the ball round finishes the query
+            else if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == Gx - 1 && y1 == Gy - 1 && z1 == Gz - 1) break;      // (cannot happen on an open grid: its whole box certifies)
+            else R = min(4 * R, 4096);                             // fewer than k points in the box: a wider one (whole grid: certified)
         }
-        const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
-        const bool certified = kth < lb;
         if (certified && a.fuse != FUSE_NONE) {
             // fused epilogue (k = 1): the query's distance joins the direction's exact sum / this wave's arg-max; no row, no tie list
             const T v0 = (T)__shfl(a.squared ? my_d : sqrt(my_d), 0, 64);

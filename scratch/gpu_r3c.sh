@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 3, call C: grid layout folded into the one-pass kernel (default build) x bbox block count; parity; config-3 trace; uneven-cloud baselines
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT
+export TMPDIR=/tmp
+for v in "" _bb512 _bb1024; do
+  export PCU_HIP_LIBRARY=$ROOT/point_cloud_utils_amd/libpcu_hip$v.so
+  for rep in 1 2; do
+    timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline > $OUT/r3c_bench${v}_$rep.json 2> $OUT/r3c_bench${v}_$rep.err
+    python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/r3c_bench${v}_$rep.json"))
+    print("lib$v rep$rep ms_per_step %.4f search_kernel_ms %.4f idx_ms %.4f parity %s" % (d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["device_ms_per_step"]["index_build"], d.get("parity",{}).get("idx_equal")))
+except Exception as e:
+    print("lib$v rep$rep FAILED", e); print(open("$OUT/r3c_bench${v}_$rep.err").read()[-1500:])
+PY
+  done
+done
+unset PCU_HIP_LIBRARY
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/r3c_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity > $OUT/r3c_trace.log 2>&1)
+python profiles/summarize_rocprof.py $(find $OUT/r3c_trace -name "*results.db" | head -1) 2>/dev/null | head -12
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "not switch" 2>&1 | tail -4
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/r3c_trace_c3 -- python $ROOT/bench.py --config c3 --steps 6 --warmup 2 --no-parity > $OUT/r3c_trace_c3.log 2>&1)
+python profiles/summarize_rocprof.py $(find $OUT/r3c_trace_c3 -name "*results.db" | head -1) 2>/dev/null | head -40
+for c in gauss cluster outlier; do timeout 300 python bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' | cut -c1-700; done

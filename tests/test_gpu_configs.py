@@ -153,7 +153,7 @@ def test_squeeze_of_singleton_shapes(pcu):
 
 SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINUE=1", "PCU_HIP_NO_SPIN=1", "PCU_HIP_NO_GRAPH=1",
             "PCU_HIP_NO_KD_SPEC=1", "PCU_HIP_NO_RESCALE=1", "PCU_HIP_KD_FULL=1", "PCU_HIP_NO_K1=1", "PCU_HIP_INDEX=atomic",
-            "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1"]
+            "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1", "PCU_HIP_NO_ESCALATE=1"]
 
 
 @pytest.mark.gpu
@@ -170,13 +170,15 @@ def test_every_environment_switch_keeps_the_results(pcu, oracle_kind, tmp_path, 
     y[:400] = x[:400]; y[400:800] = y[800:1200]
     cx = np.concatenate([rng.random((40_000, 3)), rng.normal(0.5, 0.002, (8_000, 3))]).astype(np.float32); cx[0] = [40.0, -30.0, 20.0]
     cy = np.concatenate([rng.random((30_000, 3)), rng.normal(0.5, 0.002, (9_000, 3))]).astype(np.float32)
-    np.savez(tmp_path / "in.npz", x=x, y=y, cx=cx, cy=cy)
+    fx = rng.random((30_000, 3), dtype=np.float32)                                       # queries between two far-apart dataset clusters:
+    fy = np.concatenate([rng.random((20_000, 3)) * 0.1, rng.random((20_000, 3)) * 0.1 + 0.9]).astype(np.float32)   # stragglers far from everything
+    np.savez(tmp_path / "in.npz", x=x, y=y, cx=cx, cy=cy, fx=fx, fy=fy)
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
-        "g = np.load(%r); x, y, cx, cy = g['x'], g['y'], g['cx'], g['cy']\n"
+        "g = np.load(%r); x, y, cx, cy, fx, fy = g['x'], g['y'], g['cx'], g['cy'], g['fx'], g['fy']\n"
         "out = {}\n"
         "for rep in range(2):\n"
-        "    for tag, a, b in (('u', x, y), ('c', cx, cy)):\n"
+        "    for tag, a, b in (('u', x, y), ('c', cx, cy), ('f', fx, fy)):\n"
         "        out[tag + 'd1'], out[tag + 'i1'] = pcu.k_nearest_neighbors(a, b, 1)\n"
         "        out[tag + 'd5'], out[tag + 'i5'] = pcu.k_nearest_neighbors(a, b, 5)\n"
         "        out[tag + 'h'] = np.array(pcu.hausdorff_distance(a, b, return_index=True), dtype=np.float64)\n"
@@ -190,7 +192,7 @@ def test_every_environment_switch_keeps_the_results(pcu, oracle_kind, tmp_path, 
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{name: value}), timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(tmp_path / "out.npz")
-    for tag, a, b in (("u", x, y), ("c", cx, cy)):
+    for tag, a, b in (("u", x, y), ("c", cx, cy), ("f", fx, fy)):
         for k in (1, 5):
             d0, i0 = oracle.k_nearest_neighbors(a, b, k, kind=oracle_kind)
             assert np.array_equal(got[f"{tag}i{k}"], i0), (switch, tag, k)

@@ -82,7 +82,8 @@ def _assert_knn(pcu, d, c, d0, c0):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
-    """Offset clouds, isolated clusters and anisotropic data: radius escalation and the coarse-grid fallback."""
+    """Offset clouds, isolated clusters and anisotropic data: stragglers far from any dataset point (in-kernel escalation; the
+    host-driven radius / coarse-grid passes are exercised by the PCU_HIP_NO_ESCALATE switch test)."""
     q = cloud(5, 20000, dtype, scale=0.3, offset=2.0)
     r = cloud(6, 30000, dtype)
     for k in (1, 4):
@@ -98,7 +99,7 @@ def test_shifted_scaled_clouds(pcu, oracle_kind, dtype):
         st = pcu.last_stats()
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
         _assert_knn(pcu, d, c, d0, c0)
-        assert st["n_escalated"] > 1000 and st["n_grid_builds"] > 2, st
+        assert st["n_escalated"] > 1000, st          # (finished inside the wave-per-query launch: box round -> ball round, search.h)
     h = pcu.hausdorff_distance(q, r, return_index=True)
     h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=oracle_kind)
     assert h[0] == h0[0]
