@@ -38,6 +38,39 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// Wave reductions whose result is needed in ONE lane (lane 63): six DPP steps in the vector ALU (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31)
+// instead of six ds_bpermute round trips through the LDS crossbar per value (__shfl_xor). Used where a block folds a dozen values
+// (bbox, moments, flags): k_bbox_partial, make_grid_body.
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, BOUND); }
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float old, float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND)); }
+#define PCU_DPP_STEPS(OP, ID, DPP)                                  \
+    v = OP(v, DPP<0x111, 0xf, 0xf, ID>(ID ? 0 : v, v));             \
+    v = OP(v, DPP<0x112, 0xf, 0xf, ID>(ID ? 0 : v, v));             \
+    v = OP(v, DPP<0x114, 0xf, 0xe, ID>(ID ? 0 : v, v));             \
+    v = OP(v, DPP<0x118, 0xf, 0xc, ID>(ID ? 0 : v, v));             \
+    v = OP(v, DPP<0x142, 0xa, 0xf, ID>(ID ? 0 : v, v));             \
+    v = OP(v, DPP<0x143, 0xc, 0xf, ID>(ID ? 0 : v, v));
+// (sum / or: lanes without a source add the identity 0 -- old = 0, bound_ctrl; min / max: they keep their own value -- old = v)
+__device__ __forceinline__ float red_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float red_min(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float red_max(float a, float b) { return b > a ? b : a; }
+__device__ __forceinline__ int red_or(int a, int b) { return a | b; }
+__device__ __forceinline__ float wave_sum63(float v) { PCU_DPP_STEPS(red_add, true, dpp_f) return v; }
+__device__ __forceinline__ float wave_min63(float v) { PCU_DPP_STEPS(red_min, false, dpp_f) return v; }
+__device__ __forceinline__ float wave_max63(float v) { PCU_DPP_STEPS(red_max, false, dpp_f) return v; }
+__device__ __forceinline__ unsigned wave_or63(unsigned u) { int v = (int)u; PCU_DPP_STEPS(red_or, true, dpp_i) return (unsigned)v; }
+#undef PCU_DPP_STEPS
+// double: the shuffle forms (every lane gets the result; the float64 entry points are not the ones a launch chain is tuned for)
+__device__ __forceinline__ double wave_sum63(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min63(double v) { return wave_min(v); }
+__device__ __forceinline__ double wave_max63(double v) { return wave_max(v); }
+
 // "Last block finishes the job" without __threadfence(): on gfx950 a device-scope fence is an L2 write-back +
 // invalidate (buffer_wbl2 / buffer_inv) per block, which costs more than the launch it saves. Instead the few values
 // that cross blocks are written with agent-scope atomic stores (write-through, `sc1`), the writer waits for them
@@ -140,23 +173,17 @@ __device__ __forceinline__ void bbox_body(const T* __restrict__ pts, int n, T* p
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        T a = wave_min(lo[j]), b = wave_max(hi[j]);
-        if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = b; }
+        T a = wave_min63(lo[j]), b = wave_max63(hi[j]);
+        if (lane == 63) { s_lo[wave][j] = a; s_hi[wave][j] = b; }
     }
     {
         T m[7] = {cnt, s1[0], s1[1], s1[2], s2[0], s2[1], s2[2]};
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m[q] += __shfl_xor(m[q], o, 64);
-            if (lane == 0) s_mom[wave][q] = m[q];
-        }
+        for (int q = 0; q < 7; ++q) { const T r = wave_sum63(m[q]); if (lane == 63) s_mom[wave][q] = r; }
     }
     {
-        unsigned m = 0;
-#pragma unroll
-        for (int b = 0; b < 7; ++b) if (__ballot((nf >> b) & 1u)) m |= 1u << b;
-        if (lane == 0) s_nf[wave] = m;
+        const unsigned m = wave_or63(nf);
+        if (lane == 63) s_nf[wave] = m;
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -220,39 +247,35 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
             for (int q = 0; q < 7; ++q) mom[q] += (double)partial[b * kBboxStride + 7 + q];
         }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < (nparts + 63) / 64) {            // (the other waves of a large block hold no partials: their slots are not read)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            T a = wave_min(lo[j]), c = wave_max(hi[j]);
-            if (lane == 0) { s_lo[wave][j] = a; s_hi[wave][j] = c; }
-        }
-        if (wave < (nparts + 63) / 64) {            // (waves without partials hold zeros)
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mom[q] += __shfl_xor(mom[q], o, 64);
+            for (int j = 0; j < 3; ++j) {
+                T a = wave_min63(lo[j]), c = wave_max63(hi[j]);
+                if (lane == 63) { s_lo[wave][j] = a; s_hi[wave][j] = c; }
             }
-        }
-        if (lane == 0) for (int q = 0; q < 7; ++q) s_mom[wave][q] = mom[q];
-        unsigned m = 0;
+            // (the moments are a heuristic -- see kCoreSigmas --: a wave's 64 block sums are added in T, the waves' sums in double)
 #pragma unroll
-        for (int b = 0; b < 7; ++b) if (__ballot((nf >> b) & 1u)) m |= 1u << b;
-        if (lane == 0) s_nf[wave] = m;
+            for (int q = 0; q < 7; ++q) { const T r = wave_sum63((T)mom[q]); if (lane == 63) s_mom[wave][q] = (double)r; }
+            const unsigned m = wave_or63(nf);
+            if (lane == 63) s_nf[wave] = m;
+        }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    const int nw = min((nparts + 63) / 64, NT / 64);      // waves that hold partials
     {
         unsigned m = 0;
-        for (int w = 0; w < NT / 64; ++w) m |= s_nf[w];
+        for (int w = 0; w < nw; ++w) m |= s_nf[w];
         const unsigned pinf = (m >> 1) & 7u, ninf = (m >> 4) & 7u;
         gp->nonfinite = ((m & 1u) ? kNfNaN : 0) | ((pinf & ninf) ? kNfBothInf : 0) | ((pinf | ninf) ? kNfAnyInf : 0) | (int)(m << 8);      // (bits 8..14: the raw mask, for the kd-tree's root box)
     }
     if (sentinel) put_sentinels(sentinel - n, n);
     double ext[3], mom[7] = {0, 0, 0, 0, 0, 0, 0};
     T rlo[3], rhi[3];                               // the range the grid is laid over (see kCoreSigmas)
-    for (int w = 0; w < (nparts + 63) / 64 && w < NT / 64; ++w) for (int q = 0; q < 7; ++q) mom[q] += s_mom[w][q];
+    for (int w = 0; w < nw; ++w) for (int q = 0; q < 7; ++q) mom[q] += s_mom[w][q];
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];
-        for (int w = 1; w < NT / 64; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
+        for (int w = 1; w < nw; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
         if (!(lo <= hi)) { lo = 0; hi = 0; }      // no finite value in this column
         gp->gmin[j] = lo; gp->gmax[j] = hi;
         rlo[j] = lo; rhi[j] = hi;
@@ -914,15 +937,19 @@ struct LargeJob {
 // One launch serves the indexes built back to back (both clouds of a two-sided call): njobs <= 2.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bucket_large(const LargeJob<T> j0, const LargeJob<T> j1, int njobs) {
+    // (bucket, slice) pairs dealt to the blocks: every over-full bucket is placed by kLargeSlices blocks at once and many buckets are in
+    // flight together. (A loop over the buckets with the whole grid striding each was a chain of nl dependent round trips: 111 us for
+    // the ~100 over-full buckets of a Gaussian cloud.)
+    constexpr unsigned kLargeSlices = 16;
     for (int jj = 0; jj < njobs; ++jj) {
         const LargeJob<T>& J = jj ? j1 : j0;
         const unsigned nl = *J.n_large;
         if (nl == 0) continue;
         const GridParams<T>& g = *J.gp;
-        for (unsigned l = 0; l < nl; ++l) {
-            const unsigned b = J.large_list[l];
+        for (unsigned v = blockIdx.x; v < nl * kLargeSlices; v += gridDim.x) {
+            const unsigned b = J.large_list[v / kLargeSlices], sub = v % kLargeSlices;
             const unsigned s = J.bucket_start[b], e = J.bucket_start[b + 1];
-            for (unsigned p = s + blockIdx.x * kBlock + threadIdx.x; p < e; p += gridDim.x * kBlock) {
+            for (unsigned p = s + sub * kBlock + threadIdx.x; p < e; p += kLargeSlices * kBlock) {
                 const Pt4<T> rec = J.tmp[p];
                 const unsigned pos = J.cell_start[cell_linear(g, rec.x, rec.y, rec.z)] + J.rank_tmp[p];
                 J.sorted[pos] = rec;

@@ -265,7 +265,7 @@ static void index_large_pass(const GridIndex<T>& a, const GridIndex<T>* b, hipSt
     const bool ua = a.bucketed, ub = b && b->bucketed;
     if (!ua && !ub) return;
     const LargeJob<T> ja = large_job(ua ? a : *b), jb = large_job(ua && ub ? *b : (ua ? a : *b));
-    hipLaunchKernelGGL(k_bucket_large<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, ja, jb, (ua && ub) ? 2 : 1);
+    hipLaunchKernelGGL(k_bucket_large<T>, dim3(4 * kBboxBlocks), dim3(kBlock), 0, s, ja, jb, (ua && ub) ? 2 : 1);        // (grid-strided; 256 blocks left the chip three quarters empty: 111 us on a Gaussian cloud)
     // every record is placed now: searches may use the index (GridParams::has_large)
     if (ua) (void)hipMemsetAsync(reinterpret_cast<char*>(a.gp) + offsetof(GridParams<T>, has_large), 0, sizeof(int), s);
     if (ub) (void)hipMemsetAsync(reinterpret_cast<char*>(b->gp) + offsetof(GridParams<T>, has_large), 0, sizeof(int), s);
@@ -505,17 +505,18 @@ static_assert(C_LARGE - C_SKEW == kLargeFlag, "search.h addresses the large-buck
 template <typename T>
 struct SearchScratch {
     int *u1 = nullptr, *u2 = nullptr, *u3 = nullptr, *t1 = nullptr, *tt = nullptr, *x0 = nullptr, *x1 = nullptr;
+    T* ub1 = nullptr;               // the lane pass's k-th best of every straggler in u1 (search.h: SearchArgs::ubound)
     int* counters = nullptr;
     int nq = 0;
 };
 template <typename T>
-static size_t scratch_bytes(int64_t nq) { return 7 * align_up((size_t)nq * 4, 256) + 256; }
+static size_t scratch_bytes(int64_t nq) { return 7 * align_up((size_t)nq * 4, 256) + align_up((size_t)nq * sizeof(T), 256) + 256; }
 template <typename T>
 static int scratch_alloc(Arena& a, SearchScratch<T>& sc, int64_t nq, int* counters_ext = nullptr) {
     sc.nq = (int)nq;
     if (aalloc(a, &sc.u1, (size_t)nq) || aalloc(a, &sc.u2, (size_t)nq) || aalloc(a, &sc.u3, (size_t)nq)) return -1;
     if (aalloc(a, &sc.t1, (size_t)nq) || aalloc(a, &sc.tt, (size_t)nq)) return -1;
-    if (aalloc(a, &sc.x0, (size_t)nq) || aalloc(a, &sc.x1, (size_t)nq)) return -1;
+    if (aalloc(a, &sc.x0, (size_t)nq) || aalloc(a, &sc.x1, (size_t)nq) || aalloc(a, &sc.ub1, (size_t)nq)) return -1;
     sc.counters = counters_ext;
     if (!sc.counters && aalloc(a, &sc.counters, C_N)) return -1;
     return 0;
@@ -552,7 +553,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
     a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0; a.row_out = j.row_out ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
-    a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr;
+    a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr; a.ubound = nullptr; a.qbound2 = nullptr;
     a.skew_limit = 0.f; a.skew_lo = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.qgp = j.qidx.gp;
     // unbalanced clouds (finer sub-box levels exist): a lane next to a heavy cell would scan thousands of candidates serially and hold its
@@ -588,6 +589,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.qlist = lst; a.qcount_dev = cnt; a.nq = j.qidx.n; a.R = 1;
             a.unresolved = last ? sc.u1 : (lv == 0 ? sc.x0 : sc.x1);
             a.n_unresolved = sc.counters + (last ? C_U1 : (lv == 0 ? C_X0 : C_X1));
+            if (last) a.ubound = sc.ub1;
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
             // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
             if (last && j.skew_check && j.n_fine == 0) { a.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
@@ -599,6 +601,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         }
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
         b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
+        b.qbound2 = sc.ub1;
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
         b.escalate = wave_escalates();                                           // ... and whatever it takes after that, inside the launch
         if (launch_search_wave<T>(KL, b, s)) return -1;
@@ -637,13 +640,14 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
         const SearchScratch<T>& sc = j.sc;
         a[d] = base_args(j, j.ridx);
         a[d].nq = j.qidx.n; a[d].R = 1;
-        a[d].unresolved = sc.u1; a[d].n_unresolved = sc.counters + C_U1;
+        a[d].unresolved = sc.u1; a[d].n_unresolved = sc.counters + C_U1; a[d].ubound = sc.ub1;
         a[d].ties = sc.t1; a[d].n_ties = sc.counters + C_T1;
         if (j.skew_check) { a[d].skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a[d].skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
         b[d] = base_args(j, j.ridx);
         b[d].ties = sc.tt; b[d].n_ties = sc.counters + C_TT;
         b[d].qlist = sc.t1; b[d].qcount_dev = sc.counters + C_T1; b[d].R = 1;            // possible ties -> total order, radius 1
         b[d].qlist2 = sc.u1; b[d].qcount2_dev = sc.counters + C_U1; b[d].R2 = 2;         // stragglers, radius 2
+        b[d].qbound2 = sc.ub1;
         b[d].unresolved = sc.u2; b[d].n_unresolved = sc.counters + C_U2;
         b[d].escalate = wave_escalates();
     }

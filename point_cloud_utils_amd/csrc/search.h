@@ -62,6 +62,9 @@ struct SearchArgs {
     T* out_d;                       // (nq_total, kreq) in the queries' CELL order: row qpos belongs to qsorted[qpos]
     long long* out_i;               // (nq_total, kreq)  (k_unpermute restores the caller's row order when needed)
     int* unresolved; int* n_unresolved;
+    T* ubound;                      // nullable, lane passes: ubound[i] = the k-th best d2 the lane found for unresolved[i] (max_v: fewer than k points) --
+                                    // an upper bound of the true one, which lets the wave-per-query pass start with the ball round
+    const T* qbound2;               // wave-per-query passes: those bounds for the entries of qlist2
     int* ties;       int* n_ties;         // lane passes: possible tie; wave pass: genuine tie ("true ties")
     // Fused epilogue (reduce.h, FUSE_*): instead of result rows the k = 1 lane pass writes ONE partial per block --
     // FUSE_SUM: fp64 sum of its certified lanes' distances -> f_sum[block]; FUSE_ARGMAX: their arg-max -> f_max_v / f_max_k[block]
@@ -86,16 +89,18 @@ __device__ __forceinline__ int index_not_ready(const SearchArgs<T>& a, const Gri
 
 constexpr int kLargeFlag = 3;      // counters[C_LARGE] relative to counters[C_SKEW] (pcu_hip.hip)
 
-// Append `value` for lanes with `flag` set; one atomic per wave.
-__device__ __forceinline__ void wave_append(bool flag, int value, int* list, int* counter) {
+// Append `value` for lanes with `flag` set; one atomic per wave. Returns the lane's slot (-1: not appended).
+__device__ __forceinline__ int wave_append(bool flag, int value, int* list, int* counter) {
     const unsigned long long m = __ballot(flag);
-    if (m == 0) return;
+    if (m == 0) return -1;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
     int base = 0;
     if (lane == leader) base = atomicAdd(counter, __popcll(m));
     base = __shfl(base, leader, 64);
-    if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (flag) list[slot] = value;
+    return flag ? slot : -1;
 }
 
 // Lower bound on the computed d2 of every dataset point whose cell lies outside [c0..c1] (per axis) of the grid.
@@ -244,7 +249,8 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
             if (i <= kreq && bd[i] == bd[i - 1] && bi[i] != 0x7fffffff) adj = true;
         tie = tie || adj;
     }
-    wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+    const int us = wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+    if (us >= 0 && a.ubound) a.ubound[us] = kth;
     wave_append(certified && tie, qpos, a.ties, a.n_ties);
 }
 
@@ -634,7 +640,8 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     }
     const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
     const bool certified = valid && best < lb;
-    wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+    const int us = wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+    if (us >= 0 && a.ubound) a.ubound[us] = best;
     f_ok = certified;
     f_v = a.squared ? best : sqrt(best);
     f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
@@ -676,6 +683,14 @@ __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d 
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const int n_blocks) {
     const int lane = threadIdx.x & 63;
+    // fused sum: the block's exact accumulators per direction (reduce.h: exact_add; LDS atomics, flushed once at the end)
+    __shared__ unsigned long long s_limbs[2][kAccLimbs];
+    __shared__ double s_special[2];
+    if (a0.fuse == FUSE_SUM) {
+        for (int i = threadIdx.x; i < 2 * kAccLimbs; i += kBlock) (&s_limbs[0][0])[i] = 0ull;
+        if (threadIdx.x < 2) s_special[threadIdx.x] = 0.0;
+        __syncthreads();
+    }
     // fused arg-max: this wave's best per direction (named scalars: an array indexed by the direction is promoted to LDS, and
     // addressing it needs the block dimensions, i.e. a fetch of the dispatch packet in the prologue)
     T fbv0 = -Limits<T>::max_v, fbv1 = -Limits<T>::max_v;
@@ -741,8 +756,10 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         //               Whatever the round returns is final by construction -- however far the query is from its neighbours, and
         //               without coarser grids or a host round trip per radius;
         //   wider box   if the box held fewer than k points, its radius grows four-fold (up to the whole grid).
-        T ball = Limits<T>::max_v;                  // < max_v: ball round with this bound
         const bool esc = a.escalate && !g.closed;   // (a closed sub-box level does not hold the points beyond its box: nothing to finish there)
+        // < max_v: ball round with this bound. A straggler of the lane pass brings the k-th best that pass found: no box round needed.
+        T ball = (esc && second && a.qbound2) ? a.qbound2[w - nq1] : Limits<T>::max_v;
+        if (!(ball < Limits<T>::max_v)) ball = Limits<T>::max_v;          // (NaN never: d2 of kept candidates are ordered; defensive)
         for (int round = 0;; ++round) {
             const bool is_ball = ball < Limits<T>::max_v;
             int x0, x1, y0, y1, z0, z1;
@@ -850,7 +867,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             // fused epilogue (k = 1): the query's distance joins the direction's exact sum / this wave's arg-max; no row, no tie list
             const T v0 = (T)__shfl(a.squared ? my_d : sqrt(my_d), 0, 64);
             const int i0 = __shfl(my_i, 0, 64);
-            if (a.fuse == FUSE_SUM) { if (lane == 0) exact_add(a.f_limbs, a.f_special, (double)v0); }
+            if (a.fuse == FUSE_SUM) { if (lane == 0) exact_add(s_limbs[job1 ? 1 : 0], &s_special[job1 ? 1 : 0], (double)v0); }
             else {
                 const long long key = ((long long)q.idx << 32) | (long long)((unsigned)i0 | (tie ? 0x80000000u : 0u));
                 if (job1) argmax_combine(fbv1, fbk1, v0, key); else argmax_combine(fbv0, fbk0, v0, key);
@@ -871,6 +888,19 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             if (tie && lane == 0) a.ties[atomicAdd(a.n_ties, 1)] = qpos;
         } else if (lane == 0) {
             a.unresolved[atomicAdd(a.n_unresolved, 1)] = qpos;
+        }
+    }
+    // fused sum: the block's exact accumulators go to the call's, one atomic per non-zero limb and block. (One set of global atomics
+    // per QUERY -- three words that every query of a cloud shares -- serialised at a single L2 channel: 33k stragglers of a Gaussian
+    // cloud took 600 us.)
+    if (a0.fuse == FUSE_SUM) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * (kAccLimbs + 1); i += kBlock) {
+            const int d = i / (kAccLimbs + 1), l = i % (kAccLimbs + 1);
+            if (d == 1 && njobs < 2) continue;
+            const SearchArgs<T>& a = d ? a1 : a0;
+            if (l < kAccLimbs) { const unsigned long long v = s_limbs[d][l]; if (v) atomicAdd(&a.f_limbs[l], v); }
+            else { const double v = s_special[d]; if (v != 0.0) atomicAdd(a.f_special, v); }
         }
     }
     // fused arg-max: one partial per wave and direction (every wave writes its slots, so the fold needs no counts)
