@@ -231,6 +231,10 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
     __shared__ T s_lo[NT / 64][3], s_hi[NT / 64][3];
     __shared__ double s_mom[NT / 64][7];
     __shared__ unsigned s_nf[NT / 64];
+    // (the serial part below is one thread's dependent chain on the critical path of the build: its three global loads are requested
+    // here, and it avoids double-precision divisions and roots where a float or a reciprocal will do)
+    T piv[3] = {(T)0, (T)0, (T)0};
+    if (pivot) { piv[0] = pivot[0]; piv[1] = pivot[1]; piv[2] = pivot[2]; }
     {
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
         T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
@@ -273,6 +277,7 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
     double ext[3], mom[7] = {0, 0, 0, 0, 0, 0, 0};
     T rlo[3], rhi[3];                               // the range the grid is laid over (see kCoreSigmas)
     for (int w = 0; w < nw; ++w) for (int q = 0; q < 7; ++q) mom[q] += s_mom[w][q];
+    const double inv0 = mom[0] > 0 ? 1.0 / mom[0] : 0.0;
     for (int j = 0; j < 3; ++j) {
         T lo = s_lo[0][j], hi = s_hi[0][j];
         for (int w = 1; w < nw; ++w) { lo = s_lo[w][j] < lo ? s_lo[w][j] : lo; hi = s_hi[w][j] > hi ? s_hi[w][j] : hi; }
@@ -280,8 +285,8 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
         gp->gmin[j] = lo; gp->gmax[j] = hi;
         rlo[j] = lo; rhi[j] = hi;
         if (pivot && mom[0] > 0) {
-            T pv = pivot[j]; if (!((pv < (T)0 ? -pv : pv) <= Limits<T>::max_v)) pv = (T)0;
-            const double m1 = mom[1 + j] / mom[0], var = mom[4 + j] / mom[0] - m1 * m1, sd = var > 0 ? sqrt(var) : 0.0, mu = (double)pv + m1;
+            T pv = piv[j]; if (!((pv < (T)0 ? -pv : pv) <= Limits<T>::max_v)) pv = (T)0;
+            const double m1 = mom[1 + j] * inv0, var = mom[4 + j] * inv0 - m1 * m1, sd = var > 0 ? (double)sqrtf((float)var) : 0.0, mu = (double)pv + m1;
             const T a = (T)(mu - kCoreSigmas * sd), b = (T)(mu + kCoreSigmas * sd);
             if (a <= b) {                         // (moments that overflowed give NaN: the exact box stands)
                 if (a > rlo[j] && a < hi) rlo[j] = a;
@@ -302,14 +307,15 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
         for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
         // (single precision for the root: this runs serially on one thread and any h near the target will do -- the grid only decides which
         // candidates a query looks at; every block of a one-pass build computes the same value from the same inputs)
-        const float ratio = (float)(vol / want);
+        const float ratio = (float)vol / (float)want;
         h = (double)(nd == 3 ? cbrtf(ratio) : (nd == 2 ? sqrtf(ratio) : ratio));
         if (!(h > 0.0) || !isfinite(h)) h = pow(vol / want, 1.0 / nd);          // (ratio outside the float range)
         if (h_want > 0 && h_want > h) h = h_want;             // fixed-radius searches (normals.h): cells no smaller than asked for
         for (int it = 0; it < 400; ++it) {
             double cells = 1.0;
+            const double inv_hd = 1.0 / h;                   // (a cell count one off at an exact multiple is harmless: cell_coord clamps)
             for (int j = 0; j < 3; ++j) {
-                double g = act[j] ? floor(ext[j] / h) + 1.0 : 1.0;
+                double g = act[j] ? floor(ext[j] * inv_hd) + 1.0 : 1.0;
                 if (g > 2048.0) g = 2048.0;                    // keeps row tables and int math small
                 G[j] = (int)g; cells *= g;
             }

@@ -143,6 +143,34 @@ __device__ __forceinline__ T face_lower_bound(const GridParams<T>& g, T qx, T qy
     return lb;
 }
 
+// The same bound without the distance to the data's bounding box (the o[] terms above): a weaker lower bound for queries OUTSIDE the
+// box, identical inside. The k = 1 lane pass uses it -- six face distances from values it already holds instead of six more grid
+// parameters fetched at the end of every wave; a query outside the box that it fails to certify goes to the wave-per-query pass, which
+// uses the full bound.
+template <typename T>
+__device__ __forceinline__ T face_lower_bound_inner(const GridParams<T>& g, T qx, T qy, T qz, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    const T q[3] = {qx, qy, qz};
+    const int c0[3] = {x0, y0, z0}, c1[3] = {x1, y1, z1};
+    T lb = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (c0[j] > 0 || g.closed) {
+            T m = q[j] - face_below(g, j, c0[j]);
+            m = m > (T)0 ? m * shrink : (T)0;
+            const T f = m * m;
+            lb = f < lb ? f : lb;
+        }
+        if (c1[j] < g.G[j] - 1 || g.closed) {
+            T m = face_above(g, j, c1[j]) - q[j];
+            m = m > (T)0 ? m * shrink : (T)0;
+            const T f = m * m;
+            lb = f < lb ? f : lb;
+        }
+    }
+    return lb;
+}
+
 template <typename T>
 __device__ __forceinline__ T dist2(const Pt4<T>& q, const Pt4<T>& r) {
     const T dx = q.x - r.x, dy = q.y - r.y, dz = q.z - r.z;
@@ -196,6 +224,11 @@ __device__ __forceinline__ void offer(const T d, const int id, T (&bd)[K], int (
         bool gi = true;                     // bd[K-1] > d
 #pragma unroll
         for (int i = K - 1; i > 0; --i) {
+            // Early exit, four slots at a time: once no lane of the wave has a slot above that still moves (gi: old bd[i] > d), every
+            // lower slot keeps its value (the list is sorted). Candidates met late in a scan beat the k-th best only narrowly and land
+            // in the top few slots: the K-wide chain (four 4-cycle-class instructions per slot, profiles/r03_valu_rate.txt) shrinks
+            // to its first chunk for most insertions.
+            if (K >= 8 && (i & 3) == 3 && i != K - 1) { if (!__any(gi)) break; }
             const bool gm = bd[i - 1] > d;
             bd[i] = clamp3(bd[i - 1], bd[i], d);
             bi[i] = gm ? bi[i - 1] : (gi ? id : bi[i]);
@@ -225,7 +258,7 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
         wave_append(valid, qpos, a.ties, a.n_ties);
         return;
     }
-    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const T lb = face_lower_bound_inner(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
     const int kreq = a.kreq;
     T kth = bd[0];
 #pragma unroll
@@ -257,6 +290,9 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
 // Main pass: radius R = 1 (the 27 cells around the query's cell). The 9 row bounds are fetched up front (18
 // independent loads in flight), then each row is consumed in groups of 4 candidates whose 4 loads are issued
 // together, so a lane exposes ~20 dependent memory latencies instead of ~70.
+#ifndef PCU_KBUF
+#define PCU_KBUF 12
+#endif
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     // XCD-aware block order: workgroup b is dispatched to XCD b % 8 (observed placement; speed only, never
@@ -323,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     // scan that is every candidate (k = 16: 64 of the 78 VALU instructions per candidate step). Parked candidates go through
     // the very same offer() later, against a k-th best that can only have become smaller, so results and tie flags are
     // unchanged; a wave now runs the insertion max-over-lanes-of-the-buffer-fill times per burst instead of once per step.
-    constexpr int kBuf = K > 1 ? 12 : 1;
+    constexpr int kBuf = K > 1 ? PCU_KBUF : 1;
     __shared__ T s_bd[kBuf][kBlock];
     __shared__ int s_bi[kBuf][kBlock];
     const int tid = threadIdx.x;
@@ -638,7 +674,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         wave_append(valid, qpos, a.ties, a.n_ties);
         return;
     }
-    const T lb = face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+    const T lb = face_lower_bound_inner(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
     const bool certified = valid && best < lb;
     const int us = wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
     if (us >= 0 && a.ubound) a.ubound[us] = best;
@@ -736,6 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             if (lex_less(d, id, bd[K - 1], bi[K - 1])) {
 #pragma unroll
                 for (int i = K - 1; i > 0; --i) {
+                    if (K >= 8 && (i & 3) == 3 && i != K - 1) { if (!__any(lex_less(d, id, bd[i], bi[i]))) break; }      // (see offer(): nothing below moves)
                     const bool gm = lex_less(d, id, bd[i - 1], bi[i - 1]);
                     const bool gi = lex_less(d, id, bd[i], bi[i]);
                     bd[i] = gm ? bd[i - 1] : (gi ? d : bd[i]);

@@ -1,19 +1,21 @@
 #!/bin/bash
 # Collects the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/<tag>_bench.json         bench.py line (with cpu_baseline + parity)
-#   gpurun_out/<tag>_trace/             rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/<tag>_pmc_<pass>/        rocprofv3 --pmc passes (separate runs, csv): fetch, write, tcc (raw request counters),
-#                                       sq (instruction mix, active lanes, scalar unit), sq2 (wave-cycle breakdown), ta, tcp
-#   gpurun_out/<tag>_calib_<pass>/      the same TCC passes over profiles/calib/calib_gather (known byte counts)
+#   gpurun_out/<tag>_bench.json                 headline bench.py line (with cpu_baseline + parity)
+#   gpurun_out/<tag>_trace/                     rocprofv3 --kernel-trace --stats of the headline command
+#   gpurun_out/<tag>_pmc_<pass>/                rocprofv3 --pmc passes of the headline (separate runs, csv): fetch, write, tcc, sq, sq2, ta, tcp
+#   gpurun_out/<tag>_<cfg>_trace/, _<cfg>_pmc_fetch/, _<cfg>_pmc_write/   the same trace + HBM-byte passes for every other BASELINE config
+#                                               (c1 c2 c3 c4 c5) and the uneven-cloud cases (gauss cluster outlier)
+#   gpurun_out/<tag>_calib_<pass>/              the TCC passes over profiles/calib/calib_gather (known byte counts)
+#   gpurun_out/<tag>_configs.jsonl              one bench.py --config line per config (parity checked inside the line)
 # then `python profiles/postprocess.py <tag>` (CPU side) turns them into the tracked summaries under profiles/.
 # Counter passes never carry trace domains other than --kernel-trace (gpurun refuses --pmc with sys/hip/hsa traces).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
-python $ROOT/bench.py --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python $ROOT/bench.py --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity > $OUT/${TAG}_trace.log 2>&1
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
 pass fetch FETCH_SIZE
@@ -29,10 +31,17 @@ if [ -x $ROOT/profiles/calib/calib_gather ]; then
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_calib_write -- $C > $OUT/${TAG}_calib_write.log 2>&1
   rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum --output-format csv -d $OUT/${TAG}_calib_tcc -- $C > $OUT/${TAG}_calib_tcc.log 2>&1
 fi
-tail -c 2500 $OUT/${TAG}_bench.json
-# the other BASELINE configs and the widened rows: one bench line each, parity checked inside
+tail -c 1500 $OUT/${TAG}_bench.json
+# the other BASELINE configs, the uneven clouds and the widened rows: one bench line each (parity inside), and for the
+# BASELINE configs + uneven clouds a kernel trace and the two HBM-byte counter passes of the same command
 : > $OUT/${TAG}_configs.jsonl
-for c in c2 c3 c4 c5 normals morton voxel sinkhorn; do
-  timeout 300 python $ROOT/bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' >> $OUT/${TAG}_configs.jsonl
+for c in c1 c2 c3 c4 c5 gauss cluster outlier normals morton voxel sinkhorn; do
+  timeout 400 python $ROOT/bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' >> $OUT/${TAG}_configs.jsonl
+done
+for c in c1 c2 c3 c4 c5 gauss cluster outlier; do
+  CB="python $ROOT/bench.py --config $c --steps 4 --warmup 2 --no-parity"
+  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${c}_trace -- $CB > $OUT/${TAG}_${c}_trace.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_fetch -- $CB > $OUT/${TAG}_${c}_pmc_fetch.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_write -- $CB > $OUT/${TAG}_${c}_pmc_write.log 2>&1
 done
 cut -c1-260 $OUT/${TAG}_configs.jsonl
