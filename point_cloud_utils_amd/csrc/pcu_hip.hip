@@ -290,7 +290,8 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     // When every cloud of the call takes the one-pass bucket build, its blocks lay out the grid themselves (grid.h: k_bucket_onepass)
     // and the k_make_grid launch is skipped. (bbox + grid layout in ONE launch, the last block folding the partials, was measured in
     // round 2: 16.7 us against 8.1 + 4.9 us for the two launches; removed.)
-    const bool grid_in_onepass = a.bucketed && a.one_pass && (!b || (b->bucketed && b->one_pass));
+    static const bool grid_kernel = getenv("PCU_HIP_GRID_KERNEL") != nullptr;          // (always the separate k_make_grid launch)
+    const bool grid_in_onepass = !grid_kernel && a.bucketed && a.one_pass && (!b || (b->bucketed && b->one_pass));
     {
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2, a.gp};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0, b->gp} : s0;

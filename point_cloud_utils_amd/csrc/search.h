@@ -293,6 +293,15 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
 #ifndef PCU_KBUF
 #define PCU_KBUF 12
 #endif
+#ifndef PCU_KSEARCH_PIPE
+#define PCU_KSEARCH_PIPE 1
+#endif
+
+// Measured on config 3 (k = 16, 4M-vs-4M; profiles/r03_c3_*): 14.6k VALU + 4.9k SALU + 384 vector-memory instructions per wave at 44 % active
+// lanes, 49 % of the wave-cycles waiting on memory at 4 waves per SIMD (125 VGPRs); 40 KB of code (the burst insertion is inlined at every
+// row). Tried in round 3 and not kept: forcing 5 / 6 waves per SIMD (96 VGPRs: equal; 80: spills, 1.45x slower), a larger parking buffer
+// (equal), and a collection radius that cuts the insertions while a lane's slots fill (from ~67 to ~27 per lane: kernel time unchanged,
+// 1.7x the stragglers) -- the K-wide insertion is not what bounds it.
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     // XCD-aware block order: workgroup b is dispatched to XCD b % 8 (observed placement; speed only, never
@@ -376,13 +385,18 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     for (int j = 0; j < 9; ++j) {
         if (K > 1 && __any(cnt >= kBuf / 2)) flush();        // (also gives the row pruning below a fresher k-th best)
         const unsigned e = (defer || bd[K - 1] < rlb[j]) ? rs[j] : re[j];
-        for (unsigned p = rs[j]; p < e; p += kGroup) {
-            Pt4<T> c[kGroup];
+        // The groups of a row are software-pipelined: the next group's four loads are requested before the current group is evaluated
+        // (straight-line, a lane past its row's end re-reads the sentinel), so a wait on memory covers the evaluation and the parking of
+        // a whole group. Before (one group requested and waited for per trip, PCU_KSEARCH_PIPE=0) k_search<float,16> spent 49 % of its
+        // wave-cycles waiting on memory at 4 waves per SIMD (profiles/r03_c3_*.txt).
+        auto load_group = [&](unsigned p, Pt4<T> (&c)[kGroup]) {
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
                 const unsigned idx = (p + u < e) ? p + u : sentinel;
                 c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
             }
+        };
+        auto eval_group = [&](const Pt4<T> (&c)[kGroup]) {
             if (K == 1) {
 #pragma unroll
                 for (int u = 0; u < kGroup; ++u) offer<T, K>(dist2(q, c[u]), (int)c[u].idx, bd, bi, tie);
@@ -394,6 +408,29 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
                     if (d < bd[K - 1]) { s_bd[cnt][tid] = d; s_bi[cnt][tid] = (int)c[u].idx; ++cnt; }
                 }
                 if (__any(cnt > kBuf - kGroup)) flush();
+            }
+        };
+        if (PCU_KSEARCH_PIPE && K > 1) {
+            unsigned p = rs[j];
+            if (p < e) {
+                Pt4<T> ca[kGroup], cb[kGroup];
+                load_group(p, ca);
+                for (;;) {
+                    p += kGroup;
+                    load_group(p < e ? p : sentinel, cb);      // (past the end: four sentinel records, never evaluated)
+                    eval_group(ca);
+                    if (!(p < e)) break;
+                    p += kGroup;
+                    load_group(p < e ? p : sentinel, ca);
+                    eval_group(cb);
+                    if (!(p < e)) break;
+                }
+            }
+        } else {
+            for (unsigned p = rs[j]; p < e; p += kGroup) {
+                Pt4<T> c[kGroup];
+                load_group(p, c);
+                eval_group(c);
             }
         }
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
 #   gpurun_out/<tag>_bench.json                 headline bench.py line (with cpu_baseline + parity)
-#   gpurun_out/<tag>_trace/                     rocprofv3 --kernel-trace --stats of the headline command
+#   gpurun_out/<tag>_trace_summary.txt, _trace_kernels.json   rocprofv3 --kernel-trace --stats of the headline command, summarised on the box
 #   gpurun_out/<tag>_pmc_<pass>/                rocprofv3 --pmc passes of the headline (separate runs, csv): fetch, write, tcc, sq, sq2, ta, tcp
 #   gpurun_out/<tag>_<cfg>_trace/, _<cfg>_pmc_fetch/, _<cfg>_pmc_write/   the same trace + HBM-byte passes for every other BASELINE config
 #                                               (c1 c2 c3 c4 c5) and the uneven-cloud cases (gauss cluster outlier)
@@ -15,8 +15,12 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
-python $ROOT/bench.py --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# (PCU_COLLECT_LINES / PCU_COLLECT_CONFIGS: subsets of the config lists below, for a quick check of the pipeline)
+python $ROOT/bench.py --steps 50 --warmup 5 ${PCU_COLLECT_BENCH_FLAGS:-} > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# (a rocprofv3 database is ~14 MB and gpurun brings back 64 MiB at most: every trace is summarised here and its database dropped)
+summarise() { db=$(find $OUT/$1 -name "*results.db" | head -1); python $ROOT/profiles/summarize_rocprof.py $db --json $OUT/$1_kernels.json > $OUT/$1_summary.txt 2>/dev/null; rm -rf $OUT/$1; }
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity > $OUT/${TAG}_trace.log 2>&1
+summarise ${TAG}_trace
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
@@ -35,12 +39,13 @@ tail -c 1500 $OUT/${TAG}_bench.json
 # the other BASELINE configs, the uneven clouds and the widened rows: one bench line each (parity inside), and for the
 # BASELINE configs + uneven clouds a kernel trace and the two HBM-byte counter passes of the same command
 : > $OUT/${TAG}_configs.jsonl
-for c in c1 c2 c3 c4 c5 gauss cluster outlier normals morton voxel sinkhorn; do
+for c in ${PCU_COLLECT_LINES:-c1 c2 c3 c4 c5 gauss cluster outlier normals morton voxel sinkhorn}; do
   timeout 400 python $ROOT/bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' >> $OUT/${TAG}_configs.jsonl
 done
-for c in c1 c2 c3 c4 c5 gauss cluster outlier; do
+for c in ${PCU_COLLECT_CONFIGS:-c1 c2 c3 c4 c5 gauss cluster outlier}; do
   CB="python $ROOT/bench.py --config $c --steps 4 --warmup 2 --no-parity"
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${c}_trace -- $CB > $OUT/${TAG}_${c}_trace.log 2>&1
+  summarise ${TAG}_${c}_trace
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_fetch -- $CB > $OUT/${TAG}_${c}_pmc_fetch.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_write -- $CB > $OUT/${TAG}_${c}_pmc_write.log 2>&1
 done

@@ -4,14 +4,14 @@
    profiles/hbm_traffic.json (read by bench.py: measured HBM bytes per launch + issue-side fractions of the dominant kernel)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 N_SIMD, N_CU = 1024, 256          # MI355X: 256 CUs x 4 SIMD-32
 line = [l for l in open(os.path.join(G, f"{tag}_bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
-db = max(glob.glob(os.path.join(G, f"{tag}_trace", "*", "*.db")), key=os.path.getmtime)      # (earlier collections may have left files: newest)
-txt = subprocess.run([sys.executable, os.path.join(P, "summarize_rocprof.py"), db], capture_output=True, text=True).stdout
-open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w").write(txt.replace(ROOT + "/", ""))
+# (the traces are summarised on the GPU box by collect.sh -- profiles/summarize_rocprof.py -- because the databases are too large to bring back)
+txt = open(os.path.join(G, f"{tag}_trace_summary.txt")).read()
+open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w").write(txt.replace(ROOT + "/", "").replace("/root/repo/", ""))
 
 
 def pmc(prefix, d):
@@ -82,19 +82,62 @@ if dom:
     if cyc and c.get("SQ_INSTS_VALU"):
         rep["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c.get("SQ_WAVES", 1.0)
         rep["salu_insts_per_wave"] = c.get("SQ_INSTS_SALU", 0.0) / c.get("SQ_WAVES", 1.0)
-        # "2 cycles per wave64 VALU instruction" (MI355X_MICROARCH.md, wave scheduling) is the best case; the instruction mix of the
-        # search kernels issues at 2.5-4.4 cycles (profiles/r02_ubench.txt), so this figure UNDERSTATES how busy the VALU is:
+        # "2 cycles per wave64 VALU instruction" (MI355X_MICROARCH.md, wave scheduling) is the best case (see valu_busy_frac below):
         rep["valu_issue_frac_at_2_cycles"] = 2.0 * c["SQ_INSTS_VALU"] / (N_SIMD * cyc)
         rep["salu_issue_frac"] = c.get("SQ_INSTS_SALU", 0.0) / (N_CU * cyc)     # one scalar instruction per cycle per CU
     if c.get("SQ_ACTIVE_INST_VALU"):
         rep["active_lane_frac"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        # SQ_ACTIVE_INST_VALU counts 4-cycle units (like SQ_WAVE_CYCLES: ACTIVE + WAIT_INST + WAIT = WAVE_CYCLES holds in these units)
-        rep["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc) if cyc else None
+    if cyc and c.get("SQ_INSTS_VALU"):
+        # SQ_ACTIVE_INST_VALU counts INSTRUCTIONS (it equals SQ_INSTS_VALU for every instruction kind, profiles/r03_valu_rate.txt), not busy
+        # cycles: round 2's "x 4" reading was wrong. Measured issue cost per wave64 instruction per SIMD: 2.2-2.4 cycles for the fast class
+        # (fma / add / mul / mov / and), 4.1 for the slow class (min / max / min3, compares, v_cndmask_e64, packed f32, lshl_add, or3).
+        # The VALU's busy fraction therefore lies between the two bounds; `valu_busy_frac` is the estimate for the kernel's static mix
+        # (45 % slow-class instructions: 0.55 x 2.3 + 0.45 x 4.1 = 3.1 cycles).
+        per_simd = c["SQ_INSTS_VALU"] / N_SIMD
+        rep["valu_busy_frac_bounds"] = [2.25 * per_simd / cyc, 4.1 * per_simd / cyc]
+        rep["valu_busy_frac"] = 3.1 * per_simd / cyc
+        rep["valu_cycles_per_inst_source"] = "profiles/r03_valu_rate.txt"
     if c.get("TA_BUSY_avr") and cyc:
         rep["ta_busy_frac"] = c["TA_BUSY_avr"] / cyc
     if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_WAVES"):
         rep["vmem_insts_per_wave"] = c["SQ_INSTS_VMEM_RD"] / c["SQ_WAVES"]
 json.dump(rep, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+# ---- the other configs: per-config kernel statistics, HBM bytes per launch, dominant kernel (read by bench.py --config)
+cfgk = {}
+for c_ in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier"):
+    kj = os.path.join(G, f"{tag}_{c_}_trace_kernels.json")
+    if not os.path.exists(kj):
+        continue
+    txt_c = open(os.path.join(G, f"{tag}_{c_}_trace_summary.txt")).read().split("\n\n")[0].replace("/root/repo/", "")
+    rows = [(r["name"], r["calls"], r["total_us"], r["avg_us"]) for r in json.load(open(kj))]
+    n_calls = 7                                                   # bench.py --config c --steps 4 --warmup 2: 1 initial + 2 warm-up + 4 timed calls
+    def short(n): return n.replace("void pcu::", "").replace("pcu::", "").split("(")[0]
+    fetch_c, write_c = pmc(f"{c_}_pmc", "fetch"), pmc(f"{c_}_pmc", "write")
+    ks = {}
+    for name, calls, tot, avg in rows:
+        k = short(name)
+        if not k.startswith("k_"): continue
+        f = mean(fetch_c.get(k, {}).get("FETCH_SIZE", [])); w = mean(write_c.get(k, {}).get("WRITE_SIZE", []))
+        gather = k.startswith(("k_search", "k_kd_search"))
+        ks[k] = {"calls": calls, "avg_us": avg, "total_us": tot, "launches_per_call": calls / n_calls,          # (top_kernels is in microseconds)
+                 "hbm_bytes_per_launch": f * 1024 * (f_gather if gather else f_stream) + w * 1024 * w_stream if (f or w) else None}
+    if not ks: continue
+    dom_c = max(ks, key=lambda k: ks[k]["total_us"])
+    cfgk[c_] = {"dominant": dom_c, "dominant_avg_us": ks[dom_c]["avg_us"], "dominant_launches_per_call": ks[dom_c]["launches_per_call"],
+                "dominant_hbm_bytes_per_launch": ks[dom_c]["hbm_bytes_per_launch"],
+                "gpu_us_per_call": sum(v["total_us"] for v in ks.values()) / n_calls,
+                "hbm_bytes_per_call": sum((v["hbm_bytes_per_launch"] or 0) * v["launches_per_call"] for v in ks.values()),
+                "source": f"profiles/{tag}_{c_}_kernel_stats.txt, profiles/{tag}_{c_}_pmc.txt"}
+    open(os.path.join(P, f"{tag}_{c_}_kernel_stats.txt"), "w").write(
+        f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {c_} --steps 4 --warmup 2 --no-parity ({n_calls} calls of the operator)\n" + txt_c.replace(ROOT + "/", "") + "\n")
+    lines_c = [f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --config {c_} --steps 4 --warmup 2 --no-parity`, mean per dispatch; KB, calibrated as in {tag}_pmc.txt",
+               f"# per call of the operator: GPU time {cfgk[c_]['gpu_us_per_call']:.1f} us, HBM traffic {cfgk[c_]['hbm_bytes_per_call'] / 1e6:.1f} MB; dominant kernel: {dom_c}"]
+    for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["total_us"]):
+        f = mean(fetch_c.get(k, {}).get("FETCH_SIZE", [])); w = mean(write_c.get(k, {}).get("WRITE_SIZE", []))
+        hb = v["hbm_bytes_per_launch"]
+        lines_c.append(f"{k:44s} launches/call {v['launches_per_call']:6.2f} avg_us {v['avg_us']:9.2f} FETCH_SIZE={f:11.1f} WRITE_SIZE={w:11.1f} hbm_bytes/launch={(hb if hb is not None else float('nan')):.4g}")
+    open(os.path.join(P, f"{tag}_{c_}_pmc.txt"), "w").write("\n".join(lines_c) + "\n")
+json.dump(cfgk, open(os.path.join(P, "config_kernels.json"), "w"), indent=1)
 cfg = os.path.join(G, f"{tag}_configs.jsonl")
 if os.path.exists(cfg):
     open(os.path.join(P, f"{tag}_configs.jsonl"), "w").write(open(cfg).read())

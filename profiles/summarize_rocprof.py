@@ -2,13 +2,18 @@
 """Summarise a rocprofv3 (--kernel-trace --stats) rocpd sqlite database: per-kernel calls / total / average /
 percentage, plus the kernel timeline of two consecutive bench steps from the middle of the timed region (steps without HIP
 events: bench.py brackets the search launch on every 8th step only, and its last three steps carry phase events).
-Usage: summarize_rocprof.py results.db"""
+Usage: summarize_rocprof.py results.db [--json out.json]   (--json: per-kernel calls / total_us / avg_us, for profiles/postprocess.py;
+the databases themselves are ~14 MB each and stay on the GPU box)"""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, json_out=None):
     cur = sqlite3.connect(path).cursor()
+    if json_out:
+        import json
+        json.dump([{"name": n, "calls": c, "total_us": t, "avg_us": a} for n, c, t, a in
+                   cur.execute("select name,total_calls,total_duration,average from top_kernels")], open(json_out, "w"))
     print(f"# source: {path}")
     print(f"{'kernel':100s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
     for name, calls, tot, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
@@ -28,4 +33,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--json" else None)
