@@ -829,16 +829,23 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
 
 // Start the tree's top levels ahead of need (see pcu_hip_ctx::KdSpec): called between a call's index build and its searches when the
 // context's previous large call had genuine ties. Costs GPU cycles, not wall time, when this call has none.
+// Two steps: the fork event is recorded on the caller's stream right after the index build, the tree's kernels are enqueued (on the
+// second stream, behind that event) only AFTER the call's searches: enqueued first they took the chip for themselves -- the lane pass of
+// a 4M-point call started 1.1 ms late (profiles/r03_c3_timeline.txt) -- and co-residency is impossible anyway (the k = 16 lane kernel
+// fills the register file at 4 waves per SIMD). Now the searches start at once and the tree fills their tail and the wave pass.
 template <typename T>
-static int kd_speculate(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const SearchJob<T>& j) {
+static bool kd_speculate_fork(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j) {
     static const bool off = getenv("PCU_HIP_NO_KD_SPEC") != nullptr;
-    if (off || !c->kd_spec_hint || !j.tie_order || j.ridx.n < kKdSpecMinPoints) return 0;
+    if (off || !c->kd_spec_hint || !j.tie_order || j.ridx.n < kKdSpecMinPoints) return false;
     pcu_hip_ctx::KdSpec& sp = c->kd_spec;
     if (!sp.ev_fork) {
-        HIP_TRY(hipEventCreateWithFlags(&sp.ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&sp.ev_init, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sp.ev_done, hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&sp.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sp.ev_init, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sp.ev_done, hipEventDisableTiming) != hipSuccess) return false;
     }
-    HIP_TRY(hipEventRecord(sp.ev_fork, s));             // the dataset's grid parameters (bbox = the root's) are final
+    return hipEventRecord(sp.ev_fork, s) == hipSuccess;             // the dataset's grid parameters (bbox = the root's) are final
+}
+template <typename T>
+static int kd_speculate(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const SearchJob<T>& j) {
     KdBuild<T> b; int* err = nullptr; int levels = 0;
     return kd_build_device(c, ar, s, j.d_ref_pts, j.ridx.n, j.ridx.gp, j.leaf_max, b, &err, &levels, nullptr, (const SearchJob<T>*)nullptr, 0, /*speculative=*/true);
 }
@@ -1251,8 +1258,9 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
-        if ((rc = kd_speculate(c, ar, s, job))) break;
+        const bool spec = kd_speculate_fork(c, s, job);
         if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
+        if (spec && (rc = kd_speculate(c, ar, s, job))) break;
         if (row_out) { hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError()); }
         else if ((rc = unpermute_enqueue(s, job, dd, di, rb, c->h_pinned, ++c->seq))) break;   // optimistic: redone below if stragglers / ties remain
         tm.mark(2);
