@@ -137,45 +137,100 @@ struct FuseTail {
 // host memory, sequence word last (the host spins on it, see k_pnorm_pair). Every thread requests all its inputs before the
 // first reduction -- the launch is a chain of memory round trips, not work -- and all sums run in a fixed order (thread-strided
 // partial sums, then a fixed tree), so the value is reproducible run to run.
-__device__ __forceinline__ double tail_sum(double v, double* s_buf) {      // fixed tree over the block; valid in every thread
+// The fold's sums always run in the order of kTailLanes = 1024 virtual threads -- thread-strided partial sums, a butterfly inside every 64
+// of them, the 16 wave sums added in order -- whether 1024 real threads execute it (k_fuse_tail) or the 256 of a search block
+// (k_search_wave<..., TAIL>: thread t stands for the virtual threads t, t + 256, t + 512, t + 768): both forms give the same bits.
+constexpr int kTailLanes = 1024;
+template <int NT>
+__device__ __forceinline__ double tail_sum(const double (&v)[kTailLanes / NT], double* s_buf) {      // valid in every thread
+    constexpr int V = kTailLanes / NT;
+    double w[V];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int q = 0; q < V; ++q) {
+        w[q] = v[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w[q] += __shfl_xor(w[q], o, 64);
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_buf[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) s_buf[q * (NT / 64) + (threadIdx.x >> 6)] = w[q];      // virtual wave = q * (NT / 64) + wave
+    }
     __syncthreads();
     double r = s_buf[0];
-    for (int w = 1; w < kTailThreads / 64; ++w) r += s_buf[w];
+    for (int i = 1; i < kTailLanes / 64; ++i) r += s_buf[i];
     return r;
 }
 struct VK { double v; long long k; };           // (value widened to double: exact for float, identity for double)
 __device__ __forceinline__ VK comb_max(VK a, VK b) { return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a; }
 __device__ __forceinline__ VK shfl_vk(VK a, int o) { VK r; r.v = __shfl_xor(a.v, o, 64); r.k = __shfl_xor(a.k, o, 64); return r; }
 
-template <typename T>
-__global__ __launch_bounds__(kTailThreads) void k_fuse_tail(const FuseTail<T> ft) {
-    __shared__ double s_d[kTailThreads / 64]; __shared__ double s_mv[kTailThreads / 64]; __shared__ long long s_mk[kTailThreads / 64];
+// The fold as a block-level routine of NT threads. SAME_LAUNCH: it runs in the last block of the launch that produced the wave pass's share
+// (k_search_wave<..., TAIL>): what other blocks of that launch wrote -- per-wave arg-max partials, the counters -- is read with agent-scope
+// loads (they were published with agent-scope stores / atomics; the limbs always are). The sums do not depend on NT (tail_sum).
+template <typename T, int NT, bool SAME_LAUNCH>
+__device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
+    __shared__ double s_d[kTailLanes / 64]; __shared__ double s_mv[NT / 64]; __shared__ long long s_mk[NT / 64];
     __shared__ int s_res[64]; __shared__ unsigned long long s_mask;
+    constexpr int kTailThreads = NT, V = kTailLanes / NT;
     const int tid = threadIdx.x;
-    double acc[2] = {0, 0}, term[2] = {0, 0};
+    double acc[2][V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { acc[0][q] = 0; acc[1][q] = 0; }
     VK best[2] = {{-DBL_MAX, 0x7fffffffffffffffll}, {-DBL_MAX, 0x7fffffffffffffffll}};
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {           // (constant trip count + unroll: the per-direction values stay in registers)
         if (jb >= ft.njobs) continue;
         if (ft.mode == FUSE_SUM) {
-            for (int i = tid; i < ft.nflat[jb]; i += kTailThreads) acc[jb] += ft.flat_sum[jb][i];
-            if (tid <= kAccLimbs) term[jb] = exact_term(ft.limbs[jb], ft.special[jb], tid);
+            // virtual thread vt = tid + q * NT: its strided partials (in order), then its limb term. The loads of a batch of kBatch trips
+            // of all V virtual threads are requested together and only then added, in the fixed order: a plain `acc += p[i]` loop is a
+            // chain of dependent L2 round trips (8 per thread at 1M-vs-1M, which WAS the 7 us of this fold).
+            constexpr int kBatch = 8;
+            const double* const fs = ft.flat_sum[jb]; const int nf = ft.nflat[jb];
+            for (int b0 = 0; b0 < nf; b0 += kBatch * kTailLanes) {
+                double v[V][kBatch];
+#pragma unroll
+                for (int q = 0; q < V; ++q)
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) { const int i = b0 + u * kTailLanes + tid + q * NT; v[q][u] = i < nf ? fs[i] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < V; ++q)
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) acc[jb][q] += v[q][u];          // (+ 0.0 past the end: the sum of distances is unchanged)
+            }
+#pragma unroll
+            for (int q = 0; q < V; ++q) { const int vt = tid + q * NT; if (vt <= kAccLimbs) acc[jb][q] += exact_term(ft.limbs[jb], ft.special[jb], vt); }
         } else {
-            for (int i = tid; i < ft.nflat[jb]; i += kTailThreads) { const VK c = {(double)ft.flat_v[jb][i], ft.flat_k[jb][i]}; best[jb] = comb_max(best[jb], c); }
-            for (int i = tid; i < ft.nwaves; i += kTailThreads) { const VK c = {(double)ft.wave_v[jb][i], ft.wave_k[jb][i]}; best[jb] = comb_max(best[jb], c); }
+            // (the arg-max is order-independent -- value, then the smaller key --: batches of independent loads, see above)
+            constexpr int kBatch = 8;
+            const T* const fv = ft.flat_v[jb]; const long long* const fk = ft.flat_k[jb]; const int nf = ft.nflat[jb];
+            for (int b0 = tid; b0 < nf; b0 += kBatch * kTailThreads) {
+                T v[kBatch]; long long k[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) { const int i = min(b0 + u * kTailThreads, nf - 1); v[u] = fv[i]; k[u] = fk[i]; }      // (past the end: the last entry again)
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) { const VK c = {(double)v[u], k[u]}; best[jb] = comb_max(best[jb], c); }
+            }
+            const T* const wv = ft.wave_v[jb]; const long long* const wk = ft.wave_k[jb];
+            for (int b0 = tid; b0 < ft.nwaves; b0 += kBatch * kTailThreads) {
+                T v[kBatch]; long long k[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int i = min(b0 + u * kTailThreads, ft.nwaves - 1);
+                    v[u] = SAME_LAUNCH ? peek(&wv[i]) : wv[i]; k[u] = SAME_LAUNCH ? peek(&wk[i]) : wk[i];
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) { const VK c = {(double)v[u], k[u]}; best[jb] = comb_max(best[jb], c); }
+            }
         }
     }
-    const int rbw = tid < 63 ? ft.result_block[tid] : 0;
+    const int rbw = tid < 63 ? (SAME_LAUNCH ? peek(&ft.result_block[tid]) : ft.result_block[tid]) : 0;
     if (tid == 0) s_mask = 0ull;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
         if (jb >= ft.njobs) continue;
         if (ft.mode == FUSE_SUM) {
-            const double r = tail_sum(acc[jb] + term[jb], s_d);
+            const double r = tail_sum<NT>(acc[jb], s_d);
             if (tid == 0) { *reinterpret_cast<double*>(&s_res[ft.w_sums + 2 * jb]) = r; s_mask |= 3ull << (ft.w_sums + 2 * jb); }
         } else {
             VK v = best[jb];
@@ -200,6 +255,8 @@ __global__ __launch_bounds__(kTailThreads) void k_fuse_tail(const FuseTail<T> ft
         if (tid == 63) __hip_atomic_store(&ft.host_block[63], (int)ft.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(1024) void k_fuse_tail(const FuseTail<T> ft) { fuse_tail_body<T, 1024, false>(ft); }
 
 // Hausdorff, row-based path: is the arg-max source row (ij[0], in the call's result block) one of the direction's queries
 // with a genuine tie? Only then does the returned j depend on the reference's tie order (pcu_hip.hip, hausdorff_end).

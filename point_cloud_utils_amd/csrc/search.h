@@ -753,6 +753,9 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
 template <typename T>
 __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d < d2 || (d == d2 && id < id2); }
 
+// (Measured and rejected, rounds 2 and 3: letting the block that finishes last also fold the fused call -- ticket, fuse_tail_body with
+// the block's 256 threads, hand-off to the host -- instead of the separate one-block k_fuse_tail launch: 21.4 us against 9.3 + 7.0 us.
+// The fold then runs strictly after the slowest block on a quarter of the threads; a launch boundary costs less.)
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const int n_blocks) {
     const int lane = threadIdx.x & 63;
