@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void k_hist_axis(const T* __restrict__ pts,
     for (int i = threadIdx.x; i < 3 * (kHistBins + 2); i += kBlock) partial[(size_t)blockIdx.x * 3 * (kHistBins + 2) + i] = (&h[0][0])[i];
 }
 
-__global__ __launch_bounds__(kBlock) void k_hist_merge(const unsigned* __restrict__ partial, int nblocks, unsigned* __restrict__ hist) {
+static __global__ __launch_bounds__(kBlock) void k_hist_merge(const unsigned* __restrict__ partial, int nblocks, unsigned* __restrict__ hist) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= 3 * (kHistBins + 2)) return;
     unsigned s = 0;
@@ -1098,19 +1098,24 @@ __global__ void k_make_grid_refit(GridParams<T>* gp, const GridParams<T>* base, 
 // `thresh` points, and the cell count a sub-box grid over it should get: the parent's cells inside the box times how
 // overfull the heavy cells are. Two stages: per-block partials {lo[3], hi[3], count, sum of cell counts}, one block folds.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_heavy_partial(const T* __restrict__ pts, int n, const unsigned* __restrict__ cell_of,
+__global__ __launch_bounds__(kBlock) void k_heavy_partial(const T* __restrict__ pts, int n, const GridParams<T>* __restrict__ gp, const unsigned* __restrict__ cell_of,
                                                           const unsigned* __restrict__ cell_start, unsigned thresh,
                                                           T* __restrict__ pbox, double* __restrict__ pcnt) {
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v}, hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
     double cnt = 0, sq = 0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const unsigned c = cell_of[i];
+        T v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = pts[3 * (size_t)i + j];
+        // (cell_of: what k_count stored; the bucketed builds keep no such array -- an open grid holds every point: the cell is recomputed)
+        const unsigned c = cell_of ? cell_of[i]
+                                   : (unsigned)row_run_lo(gp->G[0], grid_row(gp->G[1], grid_cell(*gp, 1, v[1]), grid_cell(*gp, 2, v[2])), grid_cell(*gp, 0, v[0]), grid_cell(*gp, 0, v[0]));
         if (c == 0xffffffffu) continue;
         const unsigned k = cell_start[c + 1] - cell_start[c];
         if (k <= thresh) continue;
         cnt += 1; sq += k;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const T v = pts[3 * (size_t)i + j]; lo[j] = v < lo[j] ? v : lo[j]; hi[j] = v > hi[j] ? v : hi[j]; }
+        for (int j = 0; j < 3; ++j) { lo[j] = v[j] < lo[j] ? v[j] : lo[j]; hi[j] = v[j] > hi[j] ? v[j] : hi[j]; }
     }
     __shared__ T s_lo[kBlock / 64][3], s_hi[kBlock / 64][3]; __shared__ double s_c[kBlock / 64], s_q[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1159,7 +1164,8 @@ __global__ void k_heavy_finish(const GridParams<T>* __restrict__ gp, const T* __
     if (t < C / occ * 0.25) t = C / occ * 0.25;
     if (t > cap) t = cap;
     if (t < 1) t = 1;
-    *out_target = t;
+    out_target[0] = t;
+    out_target[1] = C;          // (for the host: how much of the parent sits in heavy cells)
 }
 
 }  // namespace pcu

@@ -21,6 +21,11 @@
 #include "grid.h"
 #include "reduce.h"
 #include "search.h"
+namespace pcu {          // the k > 1 search kernels are compiled in search_kernels.hip (second translation unit, built in parallel)
+#define PCU_SEARCH_INST extern template
+#include "search_inst.h"
+#undef PCU_SEARCH_INST
+}
 #include "kd_order.h"
 #include "normals.h"
 #include "morton.h"
@@ -403,11 +408,16 @@ static int index_build_refit(Arena& ar, GridIndex<T>& g, const GridIndex<T>& bas
 }
 // Sub-box level over the heavy cells of `parent` (cells holding more than `thresh` points): enqueue only.
 template <typename T>
-static int index_build_heavy(Arena& ar, GridIndex<T>& g, const GridIndex<T>& parent, const T* d_pts, double occ, unsigned thresh, hipStream_t s) {
+static int index_build_heavy(Arena& ar, GridIndex<T>& g, const GridIndex<T>& parent, const T* d_pts, double occ, unsigned thresh, hipStream_t s,
+                             const double** stats_dev = nullptr) {
+    // stats_dev: device pair {cell count chosen for the level, number of points in heavy cells of the parent}
     QuantState<T>* qs = nullptr; T* pbox = nullptr; double *pcnt = nullptr, *target = nullptr;
     if (aalloc(ar, &qs, 1) || aalloc(ar, &pbox, (size_t)kBboxBlocks * 6) || aalloc(ar, &pcnt, (size_t)kBboxBlocks * 2) || aalloc(ar, &target, 2)) return -1;
-    hipLaunchKernelGGL(k_heavy_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, parent.n, parent.cell_of, parent.cell_start, thresh, pbox, pcnt);
+    // (a bucketed parent keeps no per-point cell ids -- its cell_of storage is the row -> slot table -- the kernel recomputes them)
+    hipLaunchKernelGGL(k_heavy_partial<T>, dim3(kBboxBlocks), dim3(kBlock), 0, s, d_pts, parent.n, parent.gp, parent.bucketed ? nullptr : parent.cell_of,
+                       parent.cell_start, thresh, pbox, pcnt);
     hipLaunchKernelGGL(k_heavy_finish<T>, dim3(1), dim3(64), 0, s, parent.gp, pbox, pcnt, kBboxBlocks, occ, 16.0 * 1024 * 1024, qs, target);
+    if (stats_dev) *stats_dev = target;
     return index_build_refit(ar, g, parent, d_pts, qs, (double)parent.n / occ, s, /*closed=*/true, target);
 }
 
@@ -981,22 +991,42 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         // grids sized by how unbalanced the previous one still is; the passes then run finest grid first.
         index_large_pass<T>(j.qidx, &j.ridx, s);        // (the balance check comes first in the kernels: unplaced over-full buckets
                                                         // of the query index would stop the passes below as well)
-        QuantState<T>* qs = nullptr;
-        if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
-        GridIndex<T> base, sub1, sub2;
-        if (index_build_refit(ar, base, j.ridx, j.d_ref_pts, qs, (double)j.ridx.n / j.occ, s)) return -1;
         // heavy cells (more than 8x the wanted occupancy): a sub-box grid over them, sized by how overfull they are;
         // and once more over what is still heavy in that one (tight clusters inside blobs)
         const unsigned thresh = (unsigned)(8.0 * j.occ + 8.0);
+        GridIndex<T> base, sub1, sub2;
         GridParams<T> hb;
-        HIP_TRY(hipMemcpyAsync(&hb, base.gp, sizeof hb, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (st) st->n_grid_builds += 1;
+        // First on the grid as built: its range is already the robust one (grid.h: make_grid_body clips at 3 sigma), so a cloud that
+        // is uneven because of clusters keeps it and only gains the sub-box levels -- tight-cluster Chamfer at 1M: 2 x (125 us of
+        // range histograms + 100 us of base rebuild) less. Only if most points sit in heavy cells (outliers so far out that they
+        // stretched even the clipped range: the grid itself is useless) is the base refitted to the cloud's core range first.
+        static const bool always_refit = getenv("PCU_HIP_REFIT_BASE") != nullptr;
+        const double* hs_dev = nullptr; double hs[2] = {0, 0};
+        bool keep_base = !always_refit;
+        if (keep_base) {
+            if (index_build_heavy(ar, sub1, j.ridx, j.d_ref_pts, j.occ, thresh, s, &hs_dev)) return -1;
+            HIP_TRY(hipMemcpyAsync(hs, hs_dev, sizeof hs, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&hb, j.ridx.gp, sizeof hb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            keep_base = hs[1] <= 0.5 * (double)j.ridx.n;
+            if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d heavy points %.0f, level cells %.0f: %s\n", j.ridx.n, hs[1], hs[0], keep_base ? "grid kept" : "base refit");
+            if (st) st->n_grid_builds += 1;
+        }
+        if (keep_base) {
+            base = j.ridx;
+        } else {
+            QuantState<T>* qs = nullptr;
+            if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
+            if (index_build_refit(ar, base, j.ridx, j.d_ref_pts, qs, (double)j.ridx.n / j.occ, s)) return -1;
+            HIP_TRY(hipMemcpyAsync(&hb, base.gp, sizeof hb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (st) st->n_grid_builds += 1;
+        }
         j.ridx = base; j.n_fine = 0;
         if ((double)hb.sumsq / (double)j.ridx.n > 4.0 * (j.occ + 1.0)) {       // still unbalanced after clipping the outliers
-            if (index_build_heavy(ar, sub1, base, j.d_ref_pts, j.occ, thresh, s)) return -1;
+            if (!keep_base) { if (index_build_heavy(ar, sub1, base, j.d_ref_pts, j.occ, thresh, s)) return -1; if (st) st->n_grid_builds += 1; }
             if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
-            if (st) st->n_grid_builds += 2;
+            if (st) st->n_grid_builds += 1;
             j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
         }
         j.skew_check = false;

@@ -138,8 +138,10 @@ struct FuseTail {
 // first reduction -- the launch is a chain of memory round trips, not work -- and all sums run in a fixed order (thread-strided
 // partial sums, then a fixed tree), so the value is reproducible run to run.
 // The fold's sums always run in the order of kTailLanes = 1024 virtual threads -- thread-strided partial sums, a butterfly inside every 64
-// of them, the 16 wave sums added in order -- whether 1024 real threads execute it (k_fuse_tail) or the 256 of a search block
-// (k_search_wave<..., TAIL>: thread t stands for the virtual threads t, t + 256, t + 512, t + 768): both forms give the same bits.
+// of them, the 16 wave sums added in order. k_fuse_tail runs it with 1024 real threads; a block of NT < 1024 threads gives the same bits
+// (thread t stands for the virtual threads t, t + NT, ...). Round 3 measured the NT = 256 form as the last block of the wave pass (one launch
+// less): 21.4 us against 9.3 + 7.0 us for the two launches -- the fold is a chain of dependent round trips that 4x fewer threads walk 4x
+// longer -- so only the 1024-thread kernel is built.
 constexpr int kTailLanes = 1024;
 template <int NT>
 __device__ __forceinline__ double tail_sum(const double (&v)[kTailLanes / NT], double* s_buf) {      // valid in every thread
@@ -165,10 +167,8 @@ struct VK { double v; long long k; };           // (value widened to double: exa
 __device__ __forceinline__ VK comb_max(VK a, VK b) { return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a; }
 __device__ __forceinline__ VK shfl_vk(VK a, int o) { VK r; r.v = __shfl_xor(a.v, o, 64); r.k = __shfl_xor(a.k, o, 64); return r; }
 
-// The fold as a block-level routine of NT threads. SAME_LAUNCH: it runs in the last block of the launch that produced the wave pass's share
-// (k_search_wave<..., TAIL>): what other blocks of that launch wrote -- per-wave arg-max partials, the counters -- is read with agent-scope
-// loads (they were published with agent-scope stores / atomics; the limbs always are). The sums do not depend on NT (tail_sum).
-template <typename T, int NT, bool SAME_LAUNCH>
+// The fold as a block-level routine of NT threads (the sums do not depend on NT: tail_sum).
+template <typename T, int NT>
 __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     __shared__ double s_d[kTailLanes / 64]; __shared__ double s_mv[NT / 64]; __shared__ long long s_mk[NT / 64];
     __shared__ int s_res[64]; __shared__ unsigned long long s_mask;
@@ -217,14 +217,14 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const int i = min(b0 + u * kTailThreads, ft.nwaves - 1);
-                    v[u] = SAME_LAUNCH ? peek(&wv[i]) : wv[i]; k[u] = SAME_LAUNCH ? peek(&wk[i]) : wk[i];
+                    v[u] = wv[i]; k[u] = wk[i];
                 }
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) { const VK c = {(double)v[u], k[u]}; best[jb] = comb_max(best[jb], c); }
             }
         }
     }
-    const int rbw = tid < 63 ? (SAME_LAUNCH ? peek(&ft.result_block[tid]) : ft.result_block[tid]) : 0;
+    const int rbw = tid < 63 ? ft.result_block[tid] : 0;
     if (tid == 0) s_mask = 0ull;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
@@ -256,7 +256,7 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     }
 }
 template <typename T>
-__global__ __launch_bounds__(1024) void k_fuse_tail(const FuseTail<T> ft) { fuse_tail_body<T, 1024, false>(ft); }
+__global__ __launch_bounds__(1024) void k_fuse_tail(const FuseTail<T> ft) { fuse_tail_body<T, 1024>(ft); }
 
 // Hausdorff, row-based path: is the arg-max source row (ij[0], in the call's result block) one of the direction's queries
 // with a genuine tie? Only then does the returned j depend on the reference's tie order (pcu_hip.hip, hausdorff_end).

@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const unsigned* __restrict
 }
 
 // The call's result block to pinned host memory (sequence word last), for call shapes without an unpermute launch.
-__global__ void k_result_block_to_host(const int* __restrict__ result_block, int* host_block, unsigned seq) {
+static __global__ void k_result_block_to_host(const int* __restrict__ result_block, int* host_block, unsigned seq) {
     if (threadIdx.x < 63) host_block[threadIdx.x] = result_block[threadIdx.x];
     __threadfence_system();
     if (threadIdx.x == 63) __hip_atomic_store(&host_block[63], (int)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

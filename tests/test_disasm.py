@@ -27,20 +27,43 @@ def _code_object(tmp_path):
             pytest.skip(f"{t} not in this image")
     if not os.path.exists(LIB):
         pytest.skip("libpcu_hip.so not built")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "co.gfx950")
+    # the library is linked from two translation units (pcu_hip.hip, search_kernels.hip): .hip_fatbin holds one offload bundle per unit
+    fat = str(tmp_path / "fat.bin")
     subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", LIB, fat], check=True)
-    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
-                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-    return co
+    blob, magic = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    cos = []
+    for i, a in enumerate(starts):
+        part, co = str(tmp_path / f"fat{i}.bin"), str(tmp_path / f"co{i}.gfx950")
+        open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        cos.append(co)
+    return cos
 
 
 def test_search_kernels_have_no_fused_multiply_add(tmp_path):
-    co = _code_object(tmp_path)
-    syms = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "--wide", co], capture_output=True, text=True, check=True).stdout
-    names = sorted({ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln and re.search(r"k_search|k_kd_search", ln)})
+    counts, all_names = {}, []
+    for co in _code_object(tmp_path):
+        syms = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "--wide", co], capture_output=True, text=True, check=True).stdout
+        names = sorted({ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln and re.search(r"k_search|k_kd_search", ln)})
+        all_names += names
+        _count_fma(co, names, counts)
+    names = all_names
     assert len(names) >= 20, names                    # k_search1_flat x {f32, f64} x fuse modes, k_search<K>, k_search_wave<K>, kd traversals
     assert any("k_search1_flat" in n for n in names) and any("k_search_wave" in n for n in names)
-    counts = {}
+    assert len(counts) == len(names)
+    total = 0
+    for k, c in counts.items():
+        assert not c["other"], (k, c["other"][:4])
+        assert c["fma32"] == PER_SQRT_F32 * c["sqrt32"], (k, c)
+        assert c["fma64"] == PER_RSQ_F64 * c["rsq64"], (k, c)
+        total += c["fma32"] + c["fma64"]
+    assert total > 0                                  # the guard sees the expansions it accounts for (the patterns match this ISA)
+
+
+def _count_fma(co, names, counts):
     for i in range(0, len(names), 8):
         out = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--disassemble-symbols=" + ",".join(names[i:i + 8]), co],
                              capture_output=True, text=True, check=True).stdout
@@ -62,17 +85,11 @@ def test_search_kernels_have_no_fused_multiply_add(tmp_path):
                 if m.group(1) or m.group(4) == "16": c["other"].append(ins)
                 elif m.group(4) == "32": c["fma32"] += 1
                 else: c["fma64"] += 1
-    assert len(counts) == len(names)
-    total = 0
-    for k, c in counts.items():
-        assert not c["other"], (k, c["other"][:4])
-        assert c["fma32"] == PER_SQRT_F32 * c["sqrt32"], (k, c)
-        assert c["fma64"] == PER_RSQ_F64 * c["rsq64"], (k, c)
-        total += c["fma32"] + c["fma64"]
-    assert total > 0                                  # the guard sees the expansions it accounts for (the patterns match this ISA)
 
 
 def test_every_declared_kernel_is_gfx950(tmp_path):
-    co = _code_object(tmp_path)
-    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
-    assert "amdgcn-amd-amdhsa--gfx950" in notes
+    cos = _code_object(tmp_path)
+    assert len(cos) == 2                              # pcu_hip.hip + search_kernels.hip
+    for co in cos:
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        assert "amdgcn-amd-amdhsa--gfx950" in notes

@@ -315,6 +315,45 @@ def test_unbalanced_clouds_refit_path(pcu, oracle_kind, dtype):
     assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0)
 
 
+def test_unbalanced_clouds_keep_or_refit_the_base_grid(pcu, oracle_kind, tmp_path):
+    """The refit path's two branches (pcu_hip.hip: search_finish): a tight cluster inside a uniform cloud keeps the grid as built and only
+    adds sub-box levels; a cloud whose points nearly all sit in heavy cells of that grid (a small dense core inside a thin, very wide
+    halo that stretches even the clipped range) has the base grid refitted to its core range first. Run in a child process with
+    PCU_HIP_DEBUG_SKEW so that the branch taken is witnessed; results against the oracle either way."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(12)
+    n = 120_000
+    keep_r = np.concatenate([rng.random((n * 9 // 10, 3)), rng.normal(0.5, 0.002, (n // 10, 3))]).astype(np.float32)
+    keep_q = np.concatenate([rng.random((n * 7 // 10, 3)), rng.normal(0.5, 0.002, (n * 3 // 10, 3))]).astype(np.float32)
+    refit_r = np.concatenate([rng.random((n * 8 // 10, 3)) * 0.01 + 0.5, rng.normal(0.5, 30.0, (n * 2 // 10, 3))]).astype(np.float32)
+    refit_q = np.concatenate([rng.random((n // 2, 3)) * 0.012 + 0.499, rng.normal(0.5, 30.0, (n // 10, 3))]).astype(np.float32)
+    np.savez(tmp_path / "in.npz", keep_r=keep_r, keep_q=keep_q, refit_r=refit_r, refit_q=refit_q)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
+        "g = np.load(%r); out = {}\n"
+        "for tag in ('keep', 'refit'):\n"
+        "    print('CASE', tag, file=sys.stderr, flush=True)\n"
+        "    q, r = g[tag + '_q'], g[tag + '_r']\n"
+        "    out[tag + 'd'], out[tag + 'i'] = pcu.k_nearest_neighbors(q, r, 3)\n"
+        "    c, out[tag + 'cxy'], out[tag + 'cyx'] = pcu.chamfer_distance(q, r, return_index=True)\n"
+        "np.savez(%r, **out)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), str(tmp_path / "out.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCU_HIP_DEBUG_SKEW="1"), timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr.split("CASE refit")
+    assert len(log) == 2
+    assert "grid kept" in log[0] and "base refit" not in log[0], log[0][-2000:]
+    assert "base refit" in log[1], log[1][-2000:]
+    got = np.load(tmp_path / "out.npz")
+    for tag, q, rr in (("keep", keep_q, keep_r), ("refit", refit_q, refit_r)):
+        d0, i0 = oracle.k_nearest_neighbors(q, rr, 3, kind=oracle_kind)
+        assert np.array_equal(got[tag + "i"], i0), tag
+        assert np.array_equal(got[tag + "d"].view(np.uint32), np.asarray(d0).view(np.uint32)), tag
+        _, cxy0, cyx0 = oracle.chamfer_distance(q, rr, return_index=True, kind=oracle_kind)
+        assert np.array_equal(got[tag + "cxy"], cxy0) and np.array_equal(got[tag + "cyx"], cyx0), tag
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_dense_slab_bucketed_index(pcu, oracle_kind, dtype):
     """A dense slab inside a uniform cloud: some buckets of the bucketed index build hold far more points than one
