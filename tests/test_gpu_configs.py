@@ -153,7 +153,8 @@ def test_squeeze_of_singleton_shapes(pcu):
 
 SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINUE=1", "PCU_HIP_NO_SPIN=1", "PCU_HIP_NO_GRAPH=1",
             "PCU_HIP_NO_KD_SPEC=1", "PCU_HIP_NO_RESCALE=1", "PCU_HIP_KD_FULL=1", "PCU_HIP_NO_K1=1", "PCU_HIP_INDEX=atomic",
-            "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1", "PCU_HIP_NO_ESCALATE=1", "PCU_HIP_GRID_KERNEL=1", "PCU_HIP_REFIT_BASE=1"]
+            "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1", "PCU_HIP_NO_ESCALATE=1", "PCU_HIP_GRID_KERNEL=1", "PCU_HIP_REFIT_BASE=1",
+            "PCU_HIP_PROF_BUILD=1", "PCU_HIP_PROF_KD=1"]
 
 
 @pytest.mark.gpu
