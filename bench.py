@@ -120,12 +120,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PCU_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (tests/test_gpu_multirank.py: two ranks on the
+    # one GPU of the test box). Ranks then share devices and the collectives -- scalars only -- go through gloo on host tensors; RCCL
+    # refuses two ranks on one device. The line says so in config.collectives; it is never what the driver measures.
+    share = os.environ.get("PCU_BENCH_SHARE_GPU", "0") not in ("", "0")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = torch.device("cpu") if share else dev
     distributed = world > 1
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -133,6 +143,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    args.coll_dev, args.share = coll_dev, share
     if args.config != "headline":
         return other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync_all)
 
@@ -164,13 +175,13 @@ def main():
             k_ms += st["ms_kernel_search"]; k_n += st["n_kernel_search"]
             pcu.set_timing(0)
     if distributed:   # the only collective of the job: gather the per-pair scalars (K floats per rank)
-        res_t = torch.tensor(results, dtype=torch.float32, device=dev)
+        res_t = torch.tensor(results, dtype=torch.float32, device=coll_dev)
         gathered = [torch.empty_like(res_t) for _ in range(world)]
         dist.all_gather(gathered, res_t)
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # phase breakdown (diagnostic, OUTSIDE the timed region: 3 extra steps with phase events on)
@@ -225,7 +236,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"chamfer_distance, {n}-vs-{n} fp32 U[0,1)^3 clouds, one independent pair per GPU per step, "
                                    "inputs resident in HBM, scalar results gathered once (RCCL all_gather)",
-                       "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}"},
+                       "points_per_cloud": n, "pairs_per_step": world, "parallelism": f"pairs x{world}",
+                       **({"collectives": "gloo on host tensors: REHEARSAL, ranks share GPUs (PCU_BENCH_SHARE_GPU)"} if share else {})},
             "roofline": roof,
             "device_ms_per_step": {"index_build": idx_ms, "search": srch_ms, "total": tot_ms,
                                    "note": "3 extra steps outside the timed region, phase events on"},
@@ -236,8 +248,8 @@ def main():
         ref = None
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0, N = 1 only
             out["cpu_baseline"], ref = cpu_baseline(x_h, y_h)
-        if not args.no_parity and world == 1:
-            # parity on the arrays that were timed: the reference's value and BOTH index arrays
+        if not args.no_parity:
+            # parity on the arrays that were timed (N > 1: rank 0's pair): the reference's value and BOTH index arrays
             import oracle
             if ref is None:
                 oracle.build()
@@ -331,11 +343,16 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         from point_cloud_utils_amd import batched
         pairs = {p: (torch.from_numpy(cloud(1000 + 2 * p, n, np.float32)).to(dev), torch.from_numpy(cloud(1001 + 2 * p, n, np.float32)).to(dev))
                  for p in batched.shard_pairs(total, rank, world)}
-        step = lambda: batched.batched_hausdorff(lambda p: pairs[p], total)
+        last = {}
+        def step():
+            last["rows"] = batched.batched_hausdorff(lambda p: pairs[p], total)      # (collective inside: every rank calls it)
+            return last["rows"]
         units, alg = npairs * 2 * n, npairs * 2 * 3 * 4 * 2 * n
         name = f"hausdorff_distance, {npairs} independent {n}-vs-{n} fp32 pairs per GPU (batched_hausdorff: batch entry point + one all_gather)"
         def check():
-            rows = step()
+            if "rows" not in last:
+                return {"pairs_checked": 0, "note": "no step ran"}
+            rows = last["rows"]               # rank 0 only: the rows the last timed step gathered (no further collective here)
             ok = True
             for p in sorted(pairs):          # every pair of this rank against the reference
                 h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
@@ -460,7 +477,7 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -471,7 +488,8 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         out = {"metric": f"{unit}, {name}", "value": units * world * steps / dt, "unit": unit, "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64" if cfg in ("c1", "c5") else ("i32" if cfg == "morton" else "f32"), "data": "synthetic",
-               "config": {"workload": name + ", inputs resident in HBM", "baseline_config": cfg},
+               "config": {"workload": name + ", inputs resident in HBM", "baseline_config": cfg,
+                          **({"collectives": "gloo on host tensors: REHEARSAL, ranks share GPUs (PCU_BENCH_SHARE_GPU)"} if args.share else {})},
                "roofline": config_roofline(cfg, alg, dt / steps, k_ms, k_calls),
                "parity": parity}
         print(json.dumps(out), flush=True)

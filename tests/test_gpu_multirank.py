@@ -89,3 +89,29 @@ def test_two_ranks_share_one_gpu_through_the_hip_batch_entry_points():
     for r in res:
         for p, h in r[6].items():
             assert tuple(float(v) for v in h) == tuple(res[0][2][p])                                # batch entry point == single call
+
+
+@pytest.mark.parametrize("config", ["headline", "c4"])
+def test_bench_multi_rank_launch_rehearsal(config):
+    """bench.py exactly as the driver launches it for N = 2 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 ... bench.py --gpus 2`), except that both ranks share the test box's one GPU and the scalar collectives go over gloo
+    (PCU_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one device). Checks the contract of the one JSON line rank 0 prints: n_gpus, whole-job
+    value = units of all ranks / max-over-ranks time, weak scaling, parity of the timed pairs."""
+    import json
+    import subprocess
+    small = ["--points", "200000"] if config == "headline" else []
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--config", config] + small
+    r = subprocess.run(cmd, env=dict(os.environ, PCU_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "REHEARSAL" in d["config"]["collectives"]
+    units = 2 * 200000 * 2 if config == "headline" else 32 * 2 * 262144 * 2          # query-points per step over both ranks
+    assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    par = d["parity"]
+    assert par and all(v is not False for v in par.values()), par
