@@ -511,7 +511,7 @@ static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, cons
 }
 
 // Per-direction lists and counters. Counter slots:
-enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_SKEW = 6, C_X0 = 7, C_X1 = 8, C_LARGE = 9, C_N = 12 };
+enum { C_U1 = 0, C_T1 = 1, C_U2 = 2, C_U3 = 3, C_TT = 4, C_SPARE = 5, C_SKEW = 6, C_X0 = 7, C_X1 = 8, C_LARGE = 9, C_TF0 = 10, C_TF1 = 11, C_N = 12 };
 static_assert(C_LARGE - C_SKEW == kLargeFlag, "search.h addresses the large-bucket flag relative to the skew flag");
 template <typename T>
 struct SearchScratch {
@@ -548,6 +548,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
                                                  // dataset the reference's kd-tree survives; the two-sided metrics reject all non-finite input
     bool may_rescale = false; int role = 1;      // role: which cloud of the call the dataset is (pcu_hip_ctx::occ_scale)
     GridIndex<T> fine[2]; int n_fine = 0;       // finer dataset grids for the dense parts, finest first (unbalanced clouds only)
+    int* fine_ties[2] = {nullptr, nullptr};     // possible-tie lists of the lane passes over those levels (counters C_TF0 / C_TF1)
     T* out_d = nullptr; long long* out_i = nullptr;
     SearchScratch<T> sc;
     // fused epilogue (reduce.h): per-block partials of the k = 1 lane pass instead of result rows
@@ -602,6 +603,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.n_unresolved = sc.counters + (last ? C_U1 : (lv == 0 ? C_X0 : C_X1));
             if (last) a.ubound = sc.ub1;
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
+            if (!last) { a.ties = j.fine_ties[lv]; a.n_ties = sc.counters + C_TF0 + lv; }
             // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
             if (last && j.skew_check && j.n_fine == 0) { a.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
             const bool time_it = st && c->time_kernels && lv == 0 && c->n_kev + 2 <= 8;
@@ -609,6 +611,17 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             if (launch_search_fast<T>(KF, a, j.qidx.n, s, /*open_index=*/last)) return -1;
             if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
             lst = a.unresolved; cnt = a.n_unresolved;
+            if (!last) {
+                // Possible ties of a sub-box level are put into total order ON that level: the lane pass certified them there, so every
+                // candidate of equal distance lies in the 27 cells it scanned. (Handed to the base grid -- round 2 -- each of them, a query
+                // inside the cluster, scanned the base cell that holds the whole cluster: 1400 queries x 100k points = 0.45 ms per direction
+                // on the tight-cluster Chamfer.) What this launch cannot certify falls to the host-driven passes like any straggler.
+                SearchArgs<T> w = base_args(j, j.fine[lv]);
+                w.ties = sc.tt; w.n_ties = sc.counters + C_TT;
+                w.qlist = j.fine_ties[lv]; w.qcount_dev = sc.counters + C_TF0 + lv; w.R = 1;
+                w.unresolved = sc.u2; w.n_unresolved = sc.counters + C_U2;
+                if (launch_search_wave<T>(KL, w, s)) return -1;
+            }
         }
         b.qlist = sc.t1; b.qcount_dev = sc.counters + C_T1; b.R = 1;             // possible ties -> total order, radius 1
         b.qlist2 = sc.u1; b.qcount2_dev = sc.counters + C_U1; b.R2 = 2;          // stragglers, radius 2
@@ -1028,6 +1041,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
             if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
             if (st) st->n_grid_builds += 1;
             j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
+            for (int lv = 0; lv < 2; ++lv) if (!j.fine_ties[lv] && aalloc(ar, &j.fine_ties[lv], (size_t)j.qidx.n)) return -1;
         }
         j.skew_check = false;
         if (search_enqueue(c, s, j, st)) return -1;
@@ -1036,7 +1050,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         hc = hc_redo; redone = true;
         if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d lists: after finest %d, after mid %d, after base %d; ties %d\n", j.qidx.n, hc[C_X0], hc[C_X1], hc[C_U1], hc[C_T1]);
     }
-    if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1]; }
+    if (st) { st->n_escalated += hc[C_U1]; st->n_tie_flagged += hc[C_T1] + hc[C_TF0] + hc[C_TF1]; }
     int n_left = hc[C_U2];
     if (n_left == 0) {
         if (st) st->n_tie_true += hc[C_TT];
