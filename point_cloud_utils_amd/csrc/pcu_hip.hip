@@ -601,6 +601,14 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.qlist = lst; a.qcount_dev = cnt; a.nq = j.qidx.n; a.R = 1;
             a.unresolved = last ? sc.u1 : (lv == 0 ? sc.x0 : sc.x1);
             a.n_unresolved = sc.counters + (last ? C_U1 : (lv == 0 ? C_X0 : C_X1));
+            if (!last) {
+                // a closed level serves only the queries inside its box: split the incoming list first (search.h: k_box_split), the others
+                // go straight to the next level's list
+                HIP_TRY(hipMemsetAsync(sc.counters + C_U3, 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_box_split<T>, dim3((j.qidx.n + kSplitThreads * kSplitPer - 1) / (kSplitThreads * kSplitPer)), dim3(kSplitThreads), 0, s,
+                                   j.qidx.sorted, lst, cnt, j.qidx.n, j.fine[lv].gp, sc.u3, sc.counters + C_U3, a.unresolved, a.n_unresolved);
+                a.qlist = sc.u3; a.qcount_dev = sc.counters + C_U3;
+            }
             if (last) a.ubound = sc.ub1;
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
             if (!last) { a.ties = j.fine_ties[lv]; a.n_ties = sc.counters + C_TF0 + lv; }
