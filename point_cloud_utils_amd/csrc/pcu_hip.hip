@@ -1022,39 +1022,44 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         // range histograms + 100 us of base rebuild) less. Only if most points sit in heavy cells (outliers so far out that they
         // stretched even the clipped range: the grid itself is useless) is the base refitted to the cloud's core range first.
         static const bool always_refit = getenv("PCU_HIP_REFIT_BASE") != nullptr;
-        const double* hs_dev = nullptr; double hs[2] = {0, 0};
         bool keep_base = !always_refit;
+        auto add_levels = [&](const GridIndex<T>& from, const double** hs_dev) -> int {
+            if (index_build_heavy(ar, sub1, from, j.d_ref_pts, j.occ, thresh, s, hs_dev)) return -1;
+            if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
+            if (st) st->n_grid_builds += 2;
+            j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
+            for (int lv = 0; lv < 2; ++lv) if (!j.fine_ties[lv] && aalloc(ar, &j.fine_ties[lv], (size_t)j.qidx.n)) return -1;
+            return 0;
+        };
+        j.skew_check = false;
         if (keep_base) {
-            if (index_build_heavy(ar, sub1, j.ridx, j.d_ref_pts, j.occ, thresh, s, &hs_dev)) return -1;
+            // everything enqueued at once -- both sub-box levels, the passes, the read-back of the heavy-cell statistics next to the counters:
+            // ONE host round trip for the direction (the balance metric that brought us here, > 32 x the even value, already says that
+            // levels are needed). If the statistics then say "base refit", what was enqueued is dropped.
+            const double* hs_dev = nullptr; double hs[2] = {0, 0};
+            if (add_levels(j.ridx, &hs_dev)) return -1;
+            if (search_enqueue(c, s, j, st)) return -1;
             HIP_TRY(hipMemcpyAsync(hs, hs_dev, sizeof hs, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(&hb, j.ridx.gp, sizeof hb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             keep_base = hs[1] <= 0.5 * (double)j.ridx.n;
             if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d heavy points %.0f, level cells %.0f: %s\n", j.ridx.n, hs[1], hs[0], keep_base ? "grid kept" : "base refit");
-            if (st) st->n_grid_builds += 1;
         }
-        if (keep_base) {
-            base = j.ridx;
-        } else {
+        if (!keep_base) {
             QuantState<T>* qs = nullptr;
             if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
             if (index_build_refit(ar, base, j.ridx, j.d_ref_pts, qs, (double)j.ridx.n / j.occ, s)) return -1;
             HIP_TRY(hipMemcpyAsync(&hb, base.gp, sizeof hb, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             if (st) st->n_grid_builds += 1;
+            j.ridx = base; j.n_fine = 0;
+            if ((double)hb.sumsq / (double)j.ridx.n > 4.0 * (j.occ + 1.0)) {       // still unbalanced after clipping the outliers
+                if (add_levels(base, nullptr)) return -1;
+            }
+            if (search_enqueue(c, s, j, st)) return -1;
+            HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
         }
-        j.ridx = base; j.n_fine = 0;
-        if ((double)hb.sumsq / (double)j.ridx.n > 4.0 * (j.occ + 1.0)) {       // still unbalanced after clipping the outliers
-            if (!keep_base) { if (index_build_heavy(ar, sub1, base, j.d_ref_pts, j.occ, thresh, s)) return -1; if (st) st->n_grid_builds += 1; }
-            if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
-            if (st) st->n_grid_builds += 1;
-            j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
-            for (int lv = 0; lv < 2; ++lv) if (!j.fine_ties[lv] && aalloc(ar, &j.fine_ties[lv], (size_t)j.qidx.n)) return -1;
-        }
-        j.skew_check = false;
-        if (search_enqueue(c, s, j, st)) return -1;
-        HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
         hc = hc_redo; redone = true;
         if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d lists: after finest %d, after mid %d, after base %d; ties %d\n", j.qidx.n, hc[C_X0], hc[C_X1], hc[C_U1], hc[C_T1]);
     }
@@ -1520,18 +1525,28 @@ static int fused_continue(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>
 }
 // Redo a fused call's searches through the row-based path (everything the fused attempt left behind is reset).
 template <typename T>
-static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
+static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, bool skip_search = false) {
     P.fuse = FUSE_NONE; P.xy.fuse = P.yx.fuse = FUSE_NONE;
     HIP_TRY(hipMemsetAsync(P.cb, 0, sizeof(CallBlock), s));
     if (st) { st->n_passes = 0; }
-    return pair_search_enqueue(c, s, P, st);
+    // skip_search: every direction of the fused attempt stopped at the balance check (skewed_everywhere) -- the same passes would stop
+    // there again; the caller goes straight to search_finish's refit path with the counters it already holds
+    return skip_search ? 0 : pair_search_enqueue(c, s, P, st);
+}
+// Did every direction of a failed fused attempt give up on the balance check alone?
+template <typename T>
+static bool skewed_everywhere(const PairState<T>& P, const ResultBlock& h) {
+    for (int d = 0; d < (P.two ? 2 : 1); ++d) if (!h.counters[d][C_SKEW] || h.counters[d][C_LARGE]) return false;
+    return true;
 }
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, 3 if the call is to be restarted, <0 on error.
 template <typename T>
-static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false) {
-    if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
+static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false,
+                       bool host_given = false) {
+    if (host_given) {}                          // (*host holds the counters to act on: nothing was enqueued since they were read)
+    else if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
     else if (wait_result_block(c, s)) return -1;
-    memcpy(host, c->h_pinned, sizeof(ResultBlock));
+    if (!host_given) memcpy(host, c->h_pinned, sizeof(ResultBlock));
     int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
     if (r1 < 0 || r1 == 3) return r1;
     int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1]) : 0;
@@ -1595,7 +1610,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
     int rc = 0;
     do {
         ResultBlock host;
-        bool done = false;
+        bool done = false, skewed = false;
         if (P.fuse) {
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
@@ -1606,13 +1621,14 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
             else if ((rc = fused_continue(c, ar, s, P, st, host, tie_matters)) != 0) { if (rc < 0) break; rc = 0; done = true; }
-            else if ((rc = unfuse_and_research(c, s, P, st))) break;
+            else { skewed = skewed_everywhere(P, host); if ((rc = unfuse_and_research(c, s, P, st, skewed))) break; }
         }
         if (!done) {
             for (int attempt = 0; attempt < 2; ++attempt) {
-                if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
+                const bool given = attempt == 0 && skewed;       // no searches were re-run: no epilogue to run either, straight to the refit path
+                if (!given && (rc = argmax_enqueue(c, s, P, two_sided))) break;
                 tm.mark(3);
-                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true, given); if (given && rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
                 else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
@@ -1710,7 +1726,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
     int rc = 0;
     do {
         ResultBlock host;
-        bool done = false;
+        bool done = false, skewed = false;
         if (P.fuse) {
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
@@ -1721,7 +1737,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
             else if ((rc = fused_continue(c, ar, s, P, st, host, false)) != 0) { if (rc < 0) break; rc = 0; done = true; }
-            else if ((rc = unfuse_and_research(c, s, P, st))) break;
+            else { skewed = skewed_everywhere(P, host); if ((rc = unfuse_and_research(c, s, P, st, skewed))) break; }
         }
         if (!done) {
             long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
@@ -1734,6 +1750,8 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
             const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
             for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool given = attempt == 0 && skewed;       // no searches were re-run: no epilogue to run either, straight to the refit path
+                if (given) { rc = pair_finish(c, ar, s, P, st, &host, true, true); if (rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; continue; }
                 if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
                 if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
                 // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
