@@ -934,7 +934,6 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             for (int r0 = 0; r0 < nrows; r0 += 64 / sp) {
                 const int r = r0 + (sp == 2 ? lane >> 1 : lane);
                 unsigned s = 0, e = 0;
-                int row_lo = 0, row_xa = 0, row_xb = 0, row_cy = 0, row_cz = 0;      // (for the heavy-row scan below)
                 if (r < nrows) {
                     const int cz = z0 + r / ny, cy = y0 + r % ny;
                     int xa = x0, xb = x1;
@@ -955,7 +954,6 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                     if (on) {
                         const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), xa, xb);
                         s = a.cell_start[lo]; e = a.cell_start[lo + (xb - xa + 1)];
-                        row_lo = lo; row_xa = xa; row_xb = xb; row_cy = cy; row_cz = cz;
                     }
                 }
                 const bool heavy = e - s > kHeavyRow;
@@ -977,47 +975,26 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 }
                 // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
                 // lane keeps the best of its share, the rounds below merge the lanes' lists as for light rows
-                // Cell by cell, and a cell only if it can still matter: every lane's K-th best so far bounds the query's K-th neighbour
-                // from above (the light rows of this batch are in the lists already), so a cell whose box is farther than the smallest
-                // of them holds nothing for the result -- strict '>' on rounding-safe bounds, as in the ball round: no tie is skipped.
-                // (A tight cluster in the cell NEXT to the query's: 60 % of such queries never touch it.)
+                // kH records per lane and trip, their loads issued together: one wave scanning a cell of 100k points is a chain of dependent
+                // round trips (1560 of them at one record per trip: 0.48 ms for ONE query -- the whole launch on the tight-cluster cloud).
+                // (Measured and rejected: walking a heavy row cell by cell and skipping cells beyond the lists' current bound -- no gain on
+                // the cluster cloud, whose expensive queries sit INSIDE the heavy cell, and ruinous on long sparse rows: a lattice-vs-plane
+                // pair of the randomised sweep went from milliseconds to 25 s.)
                 unsigned long long hm = __ballot(heavy && (sp == 1 || !(lane & 1)));        // (once per row)
                 while (hm) {
                     const int owner = __ffsll((long long)hm) - 1;
                     hm &= hm - 1;
-                    const int hlo = __shfl(row_lo, owner, 64), hxa = __shfl(row_xa, owner, 64), hxb = __shfl(row_xb, owner, 64);
-                    const int hcy = __shfl(row_cy, owner, 64), hcz = __shfl(row_cz, owner, 64);
-                    T hy = (T)0, hz = (T)0;
-                    if (hcy < ccy) { const T m = q.y - face_below(g, 1, hcy + 1); hy = m > (T)0 ? m * shrink : (T)0; }
-                    if (hcy > ccy) { const T m = face_above(g, 1, hcy - 1) - q.y; hy = m > (T)0 ? m * shrink : (T)0; }
-                    if (hcz < ccz) { const T m = q.z - face_below(g, 2, hcz + 1); hz = m > (T)0 ? m * shrink : (T)0; }
-                    if (hcz > ccz) { const T m = face_above(g, 2, hcz - 1) - q.z; hz = m > (T)0 ? m * shrink : (T)0; }
-                    const T hrlb = (hy * hy) + (hz * hz);
-                    const bool odd = grid_row(Gy, hcy, hcz) & 1;
-                    for (int ci = 0; ci <= hxb - hxa; ++ci) {
-                        const int cx = odd ? hxb - ci : hxa + ci;
-                        const unsigned cs = a.cell_start[hlo + ci], ce = a.cell_start[hlo + ci + 1];
-                        if (cs == ce) continue;
-                        T hx = (T)0;
-                        if (cx < ccx) { const T m = q.x - face_below(g, 0, cx + 1); hx = m > (T)0 ? m * shrink : (T)0; }
-                        if (cx > ccx) { const T m = face_above(g, 0, cx - 1) - q.x; hx = m > (T)0 ? m * shrink : (T)0; }
-                        T bw = bd[K - 1];
+                    const unsigned hs = (unsigned)__shfl((int)s, owner, 64), he = (unsigned)__shfl((int)e, owner, 64);
+                    constexpr int kH = K <= 4 ? 16 : (K <= 32 ? 8 : 2);
+                    for (unsigned p = hs + (unsigned)lane; p < he; p += 64u * kH) {
+                        Pt4<T> hc[kH];
 #pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) { const T ob = __shfl_xor(bw, o, 64); bw = ob < bw ? ob : bw; }
-                        if (bw < hrlb + (hx * hx)) continue;
-                        // kH records per lane and trip, their loads issued together: one wave scanning a cell of 100k points is a chain of
-                        // dependent round trips (1560 of them at one record per trip: 0.48 ms for ONE query, which was the whole launch)
-                        constexpr int kH = K <= 4 ? 16 : (K <= 32 ? 8 : 2);
-                        for (unsigned p = cs + (unsigned)lane; p < ce; p += 64u * kH) {
-                            Pt4<T> hc[kH];
+                        for (int u = 0; u < kH; ++u) hc[u] = a.ref[min(p + 64u * (unsigned)u, he - 1u)];
 #pragma unroll
-                            for (int u = 0; u < kH; ++u) hc[u] = a.ref[min(p + 64u * (unsigned)u, ce - 1u)];
-#pragma unroll
-                            for (int u = 0; u < kH; ++u) {
-                                const Pt4<T>& c = hc[u];
-                                const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                                take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + 64u * (unsigned)u >= ce), (int)c.idx);
-                            }
+                        for (int u = 0; u < kH; ++u) {
+                            const Pt4<T>& c = hc[u];
+                            const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                            take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + 64u * (unsigned)u >= he), (int)c.idx);
                         }
                     }
                 }
