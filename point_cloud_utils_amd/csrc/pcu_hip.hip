@@ -487,7 +487,7 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     dim3 grid(grid8(nwork, tb)), block(tb);
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
-        PCU_CASE(1) PCU_CASE(2) PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32)
+        PCU_CASE(1) case 2: PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32)      // (k = 2 keeps a list of 4: one instantiation pair less, 0.2 MB)
         default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
     }
 #undef PCU_CASE

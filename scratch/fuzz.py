@@ -40,13 +40,16 @@ for case in range(first, ncases):
     try:
         V = bool(os.environ.get('FUZZ_VERBOSE'))
         if V: print('  knn', flush=True)
-        d, c = pcu.k_nearest_neighbors(q, r, k)
+        tg = time.time(); d, c = pcu.k_nearest_neighbors(q, r, k); tg = time.time() - tg
+        if tg > 1.0: print(f'SLOW knn {tg:.2f} s', tag, pcu.last_stats(), flush=True)
         if V: print('  knn done', pcu.last_stats(), flush=True)
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
         ok = np.array_equal(c, c0) and np.array_equal(d.view(np.uint8), d0.view(np.uint8))
         if k == 1 and ok:
             if V: print('  hausdorff', flush=True)
-            h = pcu.hausdorff_distance(q, r, return_index=True); h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
+            tg = time.time(); h = pcu.hausdorff_distance(q, r, return_index=True); tg = time.time() - tg
+            if tg > 1.0: print(f'SLOW hausdorff {tg:.2f} s', tag, flush=True)
+            h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
             if V: print('  chamfer idx', flush=True)
             ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True); ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=kind)
             ok = h == h0 and np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(ch) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30
