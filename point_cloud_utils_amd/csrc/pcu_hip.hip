@@ -210,14 +210,17 @@ static int max_cells_for(int64_t n, double occ) {
     if (c > 64.0 * 1024 * 1024) c = 64.0 * 1024 * 1024;
     return (int)c;
 }
-// Bucketed build: applicable when the cells split into <= 8192 buckets of <= 4096 cells (~2k points each) and the
-// (block, bucket) reservation table stays small; otherwise (tiny or huge clouds, very coarse grids) the atomic build.
+// Bucketed build: applicable when the cells split into <= kBkMaxBuckets buckets of <= 4096 cells (~kBucketPts = 4096 expected points
+// each) and the (block, bucket) reservation table stays small; otherwise (tiny or huge clouds, very coarse grids) the atomic build.
+// Workspace of the one-pass variant: every bucket owns a fixed slot of kLargeBucket = 8192 records in `tmp`, i.e. max(n, buckets x 8192)
+// records -- about 4x the cloud at 1M points (67 MB instead of 16), bounded by kBkMaxBuckets x 8192 records (2 GiB for float64) beyond
+// which it grows with n like everything else; index_bytes() counts exactly what index_alloc() takes.
 static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     static const bool off = [] { const char* e = getenv("PCU_HIP_INDEX"); return e && strcmp(e, "atomic") == 0; }();
     if (off || n < 32768 || occ > 64.0) return false;
     const int mc = max_cells_for(n, occ);
     int sh = 5;
-    while (sh < 12 && (double)(2 << sh) * occ <= (double)kBucketPts) ++sh;             // largest bucket with <= ~kBucketPts (2048) expected points
+    while (sh < 12 && (double)(2 << sh) * occ <= (double)kBucketPts) ++sh;             // largest bucket with <= ~kBucketPts expected points
     while (sh < 12 && ((mc >> sh) + 1) > kBkMaxBuckets) ++sh;
     const int nb = (mc >> sh) + 1;
     if (nb > kBkMaxBuckets) return false;
