@@ -931,14 +931,25 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             // (2R+1)^2 <= 32 rows (radius 1 and 2, i.e. nearly every query that gets here): two lanes per row, each takes half of it --
             // the pass is a chain of dependent loads per lane, so halving the chain halves the query
             const int sp = nrows <= 32 ? 2 : 1;
-            for (int r0 = 0; r0 < nrows; r0 += 64 / sp) {
+            // Rows go in batches of 64. Between batches the bound tightens: every lane's K-th best so far bounds the query's K-th neighbour
+            // from above, so later rows are tested against the smallest of them exactly as a ball round tests against its B (rounding-safe
+            // row and cell bounds, strict comparisons: what is skipped lies beyond the bound, ties included never) -- in ball rounds B only
+            // shrinks, in box rounds a bound appears as soon as one lane holds K points. The batch around the query's own row goes first.
+            // (231k queries at offset 1000 from a 167k-point sphere, k = 16: the first box with 16 points was the whole grid and every
+            // query scanned all of it, 1.6 s; scratch/case283.py.)
+            const int step = 64 / sp, nbat = (nrows + step - 1) / step;
+            const int cb = ((min(max(ccz, z0), z1) - z0) * ny + (min(max(ccy, y0), y1) - y0)) / step;
+            T bw = Limits<T>::max_v;
+            for (int bt = 0; bt < nbat; ++bt) {
+                const int r0 = (bt == 0 ? cb : (bt <= cb ? bt - 1 : bt)) * step;
                 const int r = r0 + (sp == 2 ? lane >> 1 : lane);
+                const T bound = is_ball && !(bw < ball) ? ball : bw;
                 unsigned s = 0, e = 0;
                 if (r < nrows) {
                     const int cz = z0 + r / ny, cy = y0 + r % ny;
                     int xa = x0, xb = x1;
                     bool on = true;
-                    if (is_ball) {
+                    if (bound < Limits<T>::max_v) {
                         // distance from the query to the slab of this row (0: the query's own), as in row_lower_bounds
                         T my = (T)0, mz = (T)0;
                         if (cy < ccy) { const T m = q.y - face_below(g, 1, cy + 1); my = m > (T)0 ? m * shrink : (T)0; }
@@ -946,10 +957,11 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                         if (cz < ccz) { const T m = q.z - face_below(g, 2, cz + 1); mz = m > (T)0 ? m * shrink : (T)0; }
                         if (cz > ccz) { const T m = face_above(g, 2, cz - 1) - q.z; mz = m > (T)0 ? m * shrink : (T)0; }
                         const T rlb = (my * my) + (mz * mz);
-                        on = !(ball < rlb);
-                        const T rx2 = ball * ((T)1 + (T)8 * Limits<T>::eps) - rlb;
+                        on = !(bound < rlb);
+                        const T rx2 = bound * ((T)1 + (T)8 * Limits<T>::eps) - rlb;
                         const T rx = (rx2 > (T)0 ? sqrt(rx2) : (T)0) * ((T)1 + (T)8 * Limits<T>::eps);
-                        xa = max(grid_cell(g, 0, q.x - rx) - 1, 0); xb = min(grid_cell(g, 0, q.x + rx) + 1, Gx - 1);
+                        xa = max(grid_cell(g, 0, q.x - rx) - 1, x0); xb = min(grid_cell(g, 0, q.x + rx) + 1, x1);
+                        on = on && xa <= xb;
                     }
                     if (on) {
                         const int lo = row_run_lo(Gx, grid_row(Gy, cy, cz), xa, xb);
@@ -997,6 +1009,12 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                             take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + 64u * (unsigned)u >= he), (int)c.idx);
                         }
                     }
+                }
+                if (nbat > 1) {
+                    T t = bd[K - 1];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { const T ot = __shfl_xor(t, o, 64); t = ot < t ? ot : t; }
+                    bw = t < bw ? t : bw;
                 }
             }
             // K rounds: global lexicographic minimum of the lanes' heads; the owner pops.
