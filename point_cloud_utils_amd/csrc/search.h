@@ -934,14 +934,16 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             // Rows go in batches of 64. Between batches the bound tightens: every lane's K-th best so far bounds the query's K-th neighbour
             // from above, so later rows are tested against the smallest of them exactly as a ball round tests against its B (rounding-safe
             // row and cell bounds, strict comparisons: what is skipped lies beyond the bound, ties included never) -- in ball rounds B only
-            // shrinks, in box rounds a bound appears as soon as one lane holds K points. The batch around the query's own row goes first.
+            // shrinks, in box rounds a bound appears as soon as one lane holds K points. Batches go outward from the query's own row.
             // (231k queries at offset 1000 from a 167k-point sphere, k = 16: the first box with 16 points was the whole grid and every
             // query scanned all of it, 1.6 s; scratch/case283.py.)
             const int step = 64 / sp, nbat = (nrows + step - 1) / step;
             const int cb = ((min(max(ccz, z0), z1) - z0) * ny + (min(max(ccy, y0), y1) - y0)) / step;
             T bw = Limits<T>::max_v;
+            int b_lo = cb, b_hi = cb + 1;               // batches outward from the query's own, alternating sides
             for (int bt = 0; bt < nbat; ++bt) {
-                const int r0 = (bt == 0 ? cb : (bt <= cb ? bt - 1 : bt)) * step;
+                const bool down = b_hi >= nbat || (b_lo >= 0 && !(bt & 1));
+                const int r0 = (down ? b_lo-- : b_hi++) * step;
                 const int r = r0 + (sp == 2 ? lane >> 1 : lane);
                 const T bound = is_ball && !(bw < ball) ? ball : bw;
                 unsigned s = 0, e = 0;
