@@ -26,6 +26,19 @@ def test_header_symbols_exported():
     assert b"gfx950" in L.pcu_hip_version()
 
 
+def test_only_the_c_abi_is_exported():
+    """The dynamic symbol table holds the entry points of include/pcu_hip.h and nothing else (csrc/export.map): no kernel stubs, no C++
+    template instantiations, no torch / Python symbols -- a C-ABI boundary."""
+    import shutil
+    import subprocess
+    from point_cloud_utils_amd import _lib
+    if not shutil.which("nm"):
+        pytest.skip("nm not in this image")
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.split()[-2:-1] and ln.split()[-2] in ("T", "D", "B", "W", "V"))
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
+
+
 def test_stats_struct_size_matches_header():
     from point_cloud_utils_amd import _lib
     assert ctypes.sizeof(_lib.Stats) == 4 * 8 + 2 * 4 + 4 * 4 + 4 + 4
