@@ -27,9 +27,18 @@ def _ord_value(p):
 
 
 def _promote_pair(a, b):
-    """numpy's result type of `a - b` for the dtypes the reference meets: float32 stays float32 only against float32 (or float16)."""
+    """The dtype numpy gives `norm(a - b)` (reference: _sinkhorn.py:30-32), by numpy's own promotion table: float32 stays float32 against
+    float32 / float16 / bool / 8-bit integers, everything else is float64 (wider integers with float32, integers alone: the norm of an
+    integer array is float64). One difference: a float16 result is computed and returned in float32 (no half kernels)."""
     from . import _dtype_name, _is_torch
-    want = "float32" if all(_dtype_name(x) in ("float32", "float16") for x in (a, b)) else "float64"
+
+    def np_dtype(x):
+        try:
+            return np.dtype(_dtype_name(x))
+        except TypeError:
+            return np.dtype(np.float32)            # (torch.bfloat16 and the like: no numpy counterpart)
+    rt = np.result_type(np_dtype(a), np_dtype(b))
+    want = "float32" if rt in (np.dtype(np.float16), np.dtype(np.float32)) else "float64"
     out = []
     for x in (a, b):
         if _dtype_name(x) != want:
