@@ -1,6 +1,7 @@
 // csrc/pcu_hip.hip -- C ABI (include/pcu_hip.h) + host orchestration of the gfx950 kernels.
 //
-// One translation unit, built with:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+// One of the library's two translation units (the other, search_kernels.hip, holds the k > 1 search kernels' instantiations; recipe:
+// __graft_entry__.py), each built with:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c
 // (-ffp-contract=off is part of the numerical contract: see search.h). No PyTorch, no Python, no fallback:
 // every entry point either runs the HIP path or returns an error.
 #include <hip/hip_runtime.h>
@@ -81,7 +82,7 @@ struct pcu_hip_ctx {
     bool kd_spec_hint = false;                // sticky: the last large k_nearest_neighbors call of this context had genuine ties
     // batch entry points: independent pairs are kept in flight on `lanes` (full contexts of their own: stream, workspace, pinned
     // result block), created on first use
-    unsigned* tickets = nullptr;              // device words, zero between launches: "last block" tickets of k_bbox_grid
+    unsigned* tickets = nullptr;              // device words, zero between launches ("last block" tickets; no kernel takes one since round 3)
     double occ_scale[2] = {1.0, 1.0};         // sticky: grid resolution of the first / second cloud of a call relative to the default (rescale_wanted:
                                               // surface-like clouds want finer cells); a k_nearest_neighbors dataset counts as the second cloud
     bool two_pass = false;                    // sticky: a one-pass index build of this context overflowed a bucket slot (grid.h: k_bucket_onepass)
