@@ -971,9 +971,17 @@ static bool rescale_wanted(pcu_hip_ctx* c, const SearchJob<T>& j, hipStream_t s)
 }
 
 // Non-finite input an operator does not take (grid.h: kNf*; search.h: index_not_ready): a ValueError on the Python side.
+// What the reference answers stably is answered the same way: rows of a QUERY / SOURCE cloud with a non-finite
+// coordinate find nothing (-1 / -1.0, src/point_cloud_distance.cpp:90-93) and take part in the metrics as the reference's tails make
+// them (a -1.0 never wins Hausdorff's max, :223; Chamfer gathers through index -1 = numpy's last row, __init__.py:112-113); rows of a
+// DATASET / TARGET cloud with infinities of one sign per axis are never anybody's neighbour. Only a cloud that is searched IN and
+// holds a NaN, or +inf and -inf along one axis, has no stable answer in the reference (its kd-tree bounds become NaN).
+constexpr int kNfHard = kNfNaN | kNfBothInf;
+constexpr int PCU_NONFINITE = -1000;    // internal: a search met non-finite input its operator rejects (the caller words the error)
 static int nonfinite_error(bool metric) {
-    if (metric) return fail(PCU_HIP_ERR_INVALID, "Invalid input: the point clouds contain non-finite coordinates (NaN or inf). The reference pairs such rows through "
-                            "index -1 (numpy's last row), which is not a distance; chamfer_distance / hausdorff_distance reject them.");
+    if (metric) return fail(PCU_HIP_ERR_INVALID, "Invalid input: a point cloud that is searched in (the target; both clouds of hausdorff_distance / chamfer_distance) "
+                            "contains non-finite coordinates: NaN, or both +inf and -inf along one axis. The reference builds its kd-tree over NaN bounds for such data "
+                            "and its result depends on the traversal; not supported (non-finite source rows and single-signed infinities are handled as the reference handles them).");
     return fail(PCU_HIP_ERR_INVALID, "Invalid input: dataset_points contains NaN coordinates, or both +inf and -inf along one axis. The reference builds its kd-tree over "
                 "NaN bounds for such data and returns rows that depend on the traversal; not supported (non-finite query points and single-signed "
                 "infinities in the dataset are handled as the reference handles them).");
@@ -988,7 +996,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
     // (one D2H copy + one stream sync for the whole call in the common case)
     int hc_redo[C_N], hc_large[C_N];
     bool redone = false;
-    if (hc[C_LARGE] & 4) return nonfinite_error(j.bad_q != 0);
+    if (hc[C_LARGE] & 4) return PCU_NONFINITE;
     if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[finish] role=%d n=%d occ=%.3f may=%d skew=%d large=%d u1=%d u2=%d t1=%d\n", j.role, j.ridx.n, j.occ, (int)j.may_rescale, hc[C_SKEW], hc[C_LARGE], hc[C_U1], hc[C_U2], hc[C_T1]);
     if (hc[C_LARGE]) {
         // Every pass gave up at once because an index was not ready (GridParams::has_large).
@@ -1327,7 +1335,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         tm.mark(2);
         HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
         if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
-        if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) break;
+        if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) { if (rc == PCU_NONFINITE) rc = nonfinite_error(false); break; }
         if (rc == 3) { rc = PCU_RETRY; break; }
         if (row_out) { if (rc > 0) tm.mark(2); }
         else if (rc == 1) { if ((rc = unpermute_enqueue(s, job, dd, di))) break; tm.mark(2); }
@@ -1424,7 +1432,10 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.yx.qidx = iy; P.yx.ridx = ix; P.yx.d_ref_pts = P.dx;
     P.xy.occ = occ_y; P.yx.occ = occ_x;            // a direction's occupancy is its dataset's
     P.xy.k = P.yx.k = 1; P.xy.squared = P.yx.squared = squared;
-    P.xy.bad_r = P.xy.bad_q = P.yx.bad_r = P.yx.bad_q = kNfNaN | kNfBothInf | kNfAnyInf;
+    // Non-finite input (nonfinite_error): a cloud that is searched in must not hold NaN / both infinities along an axis; query rows may hold
+    // anything. (Both clouds of a two-sided call are searched in, each by the other direction's job.) A fused attempt, whose epilogues know
+    // nothing of unmatched rows, takes finite clouds only: it gives up on any non-finite coordinate and the call is redone row-based (below).
+    P.xy.bad_r = P.yx.bad_r = kNfHard; P.xy.bad_q = P.yx.bad_q = 0;
     job_rescale_setup(c, P.xy, P.allow_rescale, 1); job_rescale_setup(c, P.yx, P.allow_rescale, 0);
     if (aalloc(ar, &P.cb, 1)) return -1;
     P.rb = &P.cb->rb;
@@ -1440,6 +1451,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.fuse = FUSE_NONE;
     if (fuse_mode != FUSE_NONE && !no_fuse && lane_k1_job(P.xy) && (!two_sided || lane_k1_job(P.yx))) {
         P.fuse = fuse_mode;
+        P.xy.bad_r = P.xy.bad_q = P.yx.bad_r = P.yx.bad_q = kNfNaN | kNfBothInf | kNfAnyInf;
         FuseTail<T>& t = P.tail; memset(&t, 0, sizeof t);
         t.mode = fuse_mode; t.njobs = two_sided ? 2 : 1; t.nwaves = kWaveBlocks * (kBlock / 64);
         for (int d = 0; d < t.njobs; ++d) {
@@ -1527,6 +1539,24 @@ static int fused_continue(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>
     memcpy(&host, c->h_pinned, sizeof host);
     return fused_ok(P, host, tie_matters, /*stragglers_done=*/true) ? 1 : 0;
 }
+// A pass refused non-finite input (counter bit 4): the classification of both clouds (GridParams::nonfinite; [0] = x / source, [1] = y / target).
+template <typename T>
+static int pair_nonfinite_flags(hipStream_t s, const PairState<T>& P, int (&nf)[2]) {
+    const GridParams<T>* gp[2] = {P.xy.qidx.gp, P.xy.ridx.gp};
+    for (int d = 0; d < 2; ++d)
+        HIP_TRY(hipMemcpyAsync(&nf[d], reinterpret_cast<const char*>(gp[d]) + offsetof(GridParams<T>, nonfinite), sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+// ... and is it input the reference answers stably (see nonfinite_error)? Then the jobs take it from here on (row-based path).
+template <typename T>
+static bool pair_nonfinite_ok(PairState<T>& P, const int (&nf)[2]) {
+    if ((nf[1] & kNfHard) || (P.two && (nf[0] & kNfHard))) return false;
+    P.xy.bad_r = P.yx.bad_r = kNfHard; P.xy.bad_q = P.yx.bad_q = 0;
+    return true;
+}
+template <typename T>
+static bool pair_refused_nonfinite(const PairState<T>& P, const ResultBlock& h) { return ((h.counters[0][C_LARGE] | (P.two ? h.counters[1][C_LARGE] : 0)) & 4) != 0; }
 // Redo a fused call's searches through the row-based path (everything the fused attempt left behind is reset).
 template <typename T>
 static int unfuse_and_research(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, bool skip_search = false) {
@@ -1619,8 +1649,13 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
             memcpy(&host, c->h_pinned, sizeof host);
-            if ((host.counters[0][C_LARGE] | host.counters[1][C_LARGE]) & 4) { rc = nonfinite_error(true); break; }
-            if (fused_ok(P, host, tie_matters)) {
+            if (pair_refused_nonfinite(P, host)) {          // non-finite coordinates: row-based, if the reference has a stable answer
+                int nf[2];
+                if ((rc = pair_nonfinite_flags(s, P, nf))) break;
+                if (!pair_nonfinite_ok(P, nf)) { rc = nonfinite_error(true); break; }
+                if ((rc = unfuse_and_research(c, s, P, st))) break;
+            }
+            else if (fused_ok(P, host, tie_matters)) {
                 for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
@@ -1632,7 +1667,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 const bool given = attempt == 0 && skewed;       // no searches were re-run: no epilogue to run either, straight to the refit path
                 if (!given && (rc = argmax_enqueue(c, s, P, two_sided))) break;
                 tm.mark(3);
-                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true, given); if (given && rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true, given); if (rc == PCU_NONFINITE) rc = nonfinite_error(true); if (given && rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
                 else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
@@ -1728,6 +1763,18 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
     const int64_t nx = pp.nx, ny = pp.ny; const bool on_dev = pp.on_dev;
     int64_t *out_cxy = pp.out_cxy, *out_cyx = pp.out_cyx; const double p_norm = pp.p_norm;
     int rc = 0;
+    // A NaN coordinate in either cloud makes the reference's value NaN whatever its kd-tree does with it: the row's own term
+    // norm(other[corr] - row) is NaN for every corr (__init__.py:112-113), and so are the mean and the sum (:114-115) -- for every ord but 0,
+    // which counts NaN as a non-zero. So the VALUE is stable although the correspondences are not: returned as the reference returns it
+    // (no indices asked for). Everything else a search refuses (nonfinite_error) has no stable answer.
+    bool nan_result = false;
+    auto nan_rule = [&](const int (&nf)[2]) { return ((nf[0] | nf[1]) & kNfNaN) && !out_cxy && !out_cyx && p_norm != 0.0; };
+    auto refused = [&]() -> int {           // a row-based search refused its dataset: the NaN value, or the error
+        int nf[2];
+        if (int r = pair_nonfinite_flags(s, P, nf)) return r;
+        if (nan_rule(nf)) { nan_result = true; return 0; }
+        return nonfinite_error(true);
+    };
     do {
         ResultBlock host;
         bool done = false, skewed = false;
@@ -1735,8 +1782,13 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
             memcpy(&host, c->h_pinned, sizeof host);
-            if ((host.counters[0][C_LARGE] | host.counters[1][C_LARGE]) & 4) { rc = nonfinite_error(true); break; }
-            if (fused_ok(P, host, false)) {
+            if (pair_refused_nonfinite(P, host)) {          // non-finite coordinates: see below (nan_rule) and hausdorff_end
+                int nf[2];
+                if ((rc = pair_nonfinite_flags(s, P, nf))) break;
+                if (!pair_nonfinite_ok(P, nf)) { if (nan_rule(nf)) { rc = 0; nan_result = true; } else rc = nonfinite_error(true); break; }
+                if ((rc = unfuse_and_research(c, s, P, st))) break;
+            }
+            else if (fused_ok(P, host, false)) {
                 for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
@@ -1755,7 +1807,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
             for (int attempt = 0; attempt < 2; ++attempt) {
                 const bool given = attempt == 0 && skewed;       // no searches were re-run: no epilogue to run either, straight to the refit path
-                if (given) { rc = pair_finish(c, ar, s, P, st, &host, true, true); if (rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; continue; }
+                if (given) { rc = pair_finish(c, ar, s, P, st, &host, true, true); if (rc == PCU_NONFINITE) { rc = refused(); break; } if (rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; continue; }
                 if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
                 if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
                 // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
@@ -1765,10 +1817,10 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                                    reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
                 HIP_TRY(hipGetLastError());
                 tm.mark(3);
-                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }
+                if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == PCU_NONFINITE) { rc = refused(); break; } if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }
                 else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
             }
-            if (rc) break;
+            if (rc || nan_result) break;
             if (!on_dev) {
                 if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, dst_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
                 if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, dst_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
@@ -1780,6 +1832,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
         out_mean2[1] = hs[1] / (double)ny;
         if (st) { st->n_queries = nx + ny; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 3); collect_kernel_times(c, st); }
     } while (0);
+    if (!rc && nan_result) { out_mean2[0] = out_mean2[1] = std::numeric_limits<double>::quiet_NaN(); if (st) st->n_queries = nx + ny; }
     ctx_end(c);
     if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;

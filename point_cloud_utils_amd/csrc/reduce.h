@@ -305,27 +305,42 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
     double s = 0;
     const bool skip = sd.giveup && (sd.giveup[0] | sd.giveup[3]);      // ([3]: kLargeFlag of search.h)
     const int n_all = skip ? 0 : sd.n;
+    // One query's norm from its correspondence, numpy.linalg.norm(tgt[corr] - q, ord, axis=-1) operation by operation in T. A query the
+    // search could not match (non-finite coordinates: src/point_cloud_distance.cpp:90-93 writes -1) is paired as the reference's Python
+    // tail pairs it -- `x[corrs]` with corrs == -1 is numpy's LAST row (__init__.py:112-113) -- and its difference vector carries the
+    // infinities / NaNs into the mean exactly as there.
+    auto from_corr = [&](int i) -> T {
+        long long c = sd.corr[i];
+        if (c == -1ll) c = sd.n_tgt - 1;
+        if ((unsigned long long)c >= (unsigned long long)sd.n_tgt) c = 0;          // (see PnormSide::n_tgt)
+        const Pt4<T> q = sd.qsorted[i];
+        const T a = sd.tgt[3 * c] - q.x, b = sd.tgt[3 * c + 1] - q.y, e = sd.tgt[3 * c + 2] - q.z;
+        const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
+        const bool any_nan = a != a || b != b || e != e;
+        T v;
+        if (pcode == P_TWO) v = sqrt(((a * a) + (b * b)) + (e * e));
+        else if (pcode == P_ONE) v = (aa + ab) + ae;
+        else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; if (any_nan) v = a + b + e; }        // (numpy's max / min propagate NaN)
+        else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; if (any_nan) v = a + b + e; }
+        else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));
+        else v = (T)pow((double)(T)((T)pow((double)aa, p) + (T)pow((double)ab, p)) + (double)(T)pow((double)ae, p), 1.0 / p);
+        return v;
+    };
     const int n_vec = pcode == P_TWO ? (n_all & ~3) : 0;       // p = 2: the distances themselves, four per 16/32-byte load
     for (int i = 4 * (bid * kBlock + (int)threadIdx.x); i < n_vec; i += 4 * sd.nb * kBlock) {
-        const T v0 = sd.d[i], v1 = sd.d[i + 1], v2 = sd.d[i + 2], v3 = sd.d[i + 3];
+        T v0 = sd.d[i], v1 = sd.d[i + 1], v2 = sd.d[i + 2], v3 = sd.d[i + 3];
+        if (v0 < (T)0 || v1 < (T)0 || v2 < (T)0 || v3 < (T)0) {         // -1.0: an unmatched query (rare)
+            if (v0 < (T)0) v0 = from_corr(i);
+            if (v1 < (T)0) v1 = from_corr(i + 1);
+            if (v2 < (T)0) v2 = from_corr(i + 2);
+            if (v3 < (T)0) v3 = from_corr(i + 3);
+        }
         s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
     }
     for (int i = n_vec + bid * kBlock + (int)threadIdx.x; i < n_all; i += sd.nb * kBlock) {
         T v;
-        if (pcode == P_TWO) {
-            v = sd.d[i];
-        } else {
-            long long c = sd.corr[i];
-            if ((unsigned long long)c >= (unsigned long long)sd.n_tgt) c = 0;          // (see PnormSide::n_tgt)
-            const Pt4<T> q = sd.qsorted[i];
-            const T a = sd.tgt[3 * c] - q.x, b = sd.tgt[3 * c + 1] - q.y, e = sd.tgt[3 * c + 2] - q.z;
-            const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
-            if (pcode == P_ONE) v = (aa + ab) + ae;
-            else if (pcode == P_INF) { v = aa > ab ? aa : ab; v = v > ae ? v : ae; }
-            else if (pcode == P_NINF) { v = aa < ab ? aa : ab; v = v < ae ? v : ae; }
-            else if (pcode == P_ZERO) v = (T)((a != 0) + (b != 0) + (e != 0));
-            else v = (T)pow((double)(T)((T)pow((double)aa, p) + (T)pow((double)ab, p)) + (double)(T)pow((double)ae, p), 1.0 / p);
-        }
+        if (pcode == P_TWO) { v = sd.d[i]; if (v < (T)0) v = from_corr(i); }
+        else v = from_corr(i);
         s += (double)v;
     }
     const double r = block_sum(s);

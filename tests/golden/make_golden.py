@@ -53,12 +53,54 @@ def nonfinite_cases():
     for name, c in cases.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)
     print("wrote", len(cases), "non-finite fixtures")
+    nonfinite_metric_cases(rng)
     # BASELINE config 1: chamfer_distance of two 10k-point fp64 clouds through the reference's CPU path (inputs are seeded, not stored)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import cloud
     x, y = cloud(1000, 10_000, np.float64), cloud(1001, 10_000, np.float64)
     ch, cxy, cyx = oracle.chamfer_distance(x, y, return_index=True, kind="ref")
     np.savez_compressed(os.path.join(HERE, "config1.npz"), chamfer=np.float64(ch), cxy=cxy, cyx=cyx)
+
+
+P_NORMS = (2, 1, np.inf, -np.inf, 0, 3)
+
+
+def nonfinite_metric_cases(rng):
+    """nf_{f32,f64}_metrics.npz: the metrics on clouds with non-finite rows, where the reference has a stable answer
+    (src/point_cloud_distance.cpp:90-93,223 and __init__.py:112-115: unmatched source rows carry -1 / -1.0, Hausdorff's max ignores
+    them, Chamfer gathers through index -1). Cases: `inf` (single-signed infinities in x), `mixed` (+inf and -inf on different axes),
+    `last` (additionally y's LAST row infinite: the gather through -1 meets inf - inf = NaN), `nan` (NaN rows in x: one-sided x -> y is
+    stable, and so is Chamfer's VALUE -- NaN -- for every ord but 0), `allbad` (no finite source row: (-1.0, 0, -1))."""
+    import warnings
+    warnings.simplefilter("ignore")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        out = {}
+        x = rng.random((900, 3), dtype=dt); y = rng.random((700, 3), dtype=dt)
+        xi = x.copy(); xi[5, 0] = np.inf; xi[100, 1] = np.inf; xi[899, 2] = np.inf; xi[40] = np.inf
+        xm = xi.copy(); xm[9, 2] = -np.inf; xm[10, 2] = -np.inf
+        yl = y.copy(); yl[-1, 0] = np.inf
+        xn = x.copy(); xn[7, 1] = np.nan; xn[50] = np.nan; xn[51, 0] = np.inf
+        for name, a, b in (("inf", xi, y), ("mixed", xm, y), ("last", xi, yl)):
+            out[f"{name}_x"] = a; out[f"{name}_y"] = b
+            out[f"{name}_os_xy"] = np.array(oracle.one_sided_hausdorff_distance(a, b, kind="ref"), np.float64)
+            out[f"{name}_os_yx"] = np.array(oracle.one_sided_hausdorff_distance(b, a, kind="ref"), np.float64)
+            out[f"{name}_os_xy_sq"] = np.array(oracle.one_sided_hausdorff_distance(a, b, squared_distances=True, kind="ref"), np.float64)
+            out[f"{name}_h"] = np.array(oracle.hausdorff_distance(a, b, True, kind="ref"), np.float64)
+            out[f"{name}_h_rev"] = np.array(oracle.hausdorff_distance(b, a, True, kind="ref"), np.float64)
+            ch, cxy, cyx = oracle.chamfer_distance(a, b, return_index=True, kind="ref")
+            out[f"{name}_cxy"] = cxy; out[f"{name}_cyx"] = cyx
+            out[f"{name}_ch"] = np.array([oracle.chamfer_distance(a, b, p_norm=p, kind="ref") for p in P_NORMS], np.float64)
+            out[f"{name}_ch_rev"] = np.array([oracle.chamfer_distance(b, a, p_norm=p, kind="ref") for p in P_NORMS], np.float64)
+        out["nan_x"] = xn; out["nan_y"] = y
+        out["nan_os_xy"] = np.array(oracle.one_sided_hausdorff_distance(xn, y, kind="ref"), np.float64)
+        for leaf in (1, 33):      # (stable: the same for every tree)
+            assert oracle.one_sided_hausdorff_distance(xn, y, max_points_per_leaf=leaf, kind="ref") == tuple(out["nan_os_xy"])
+        out["nan_ch"] = np.array([oracle.chamfer_distance(xn, y, p_norm=p, kind="ref") for p in P_NORMS if p != 0], np.float64)
+        assert np.isnan(out["nan_ch"]).all() and np.isnan(oracle.chamfer_distance(y, xn, kind="ref"))
+        bad = np.full((12, 3), np.nan, dt); bad[3] = np.inf
+        out["allbad_os"] = np.array(oracle.one_sided_hausdorff_distance(bad, y, kind="ref"), np.float64)
+        np.savez_compressed(os.path.join(HERE, f"nf_{tag}_metrics.npz"), **out)
+    print("wrote the non-finite metric fixtures")
 
 
 def main():

@@ -489,8 +489,8 @@ def test_nonfinite_inputs(pcu, oracle_kind, dtype):
     """NaN / inf coordinates (golden fixtures nf_* cover the small sizes): query rows with a non-finite coordinate find nothing
     (-1 / -1.0, src/point_cloud_distance.cpp:90-93 via nanoflann.hpp:1563), dataset points with a single-signed infinity are never a
     neighbour -- as the reference, at sizes that take the lane-per-query kernels. What breaks the reference's kd-tree (NaN in the
-    dataset, +inf and -inf along one axis: its bounds become NaN and its rows depend on the traversal) raises ValueError, and so
-    does any non-finite coordinate in chamfer_distance / hausdorff_distance (the reference pairs such rows through index -1)."""
+    dataset, +inf and -inf along one axis: its bounds become NaN and its rows depend on the traversal) raises ValueError, also in
+    chamfer_distance / hausdorff_distance when such a cloud is searched in."""
     rng = np.random.default_rng(77)
     n, m = 120_000, 90_000
     q = rng.random((n, 3)).astype(dtype); r = rng.random((m, 3)).astype(dtype)
@@ -520,9 +520,11 @@ def test_nonfinite_inputs(pcu, oracle_kind, dtype):
             pcu.k_nearest_neighbors(ok[:100], rb, 200)  # k > 127: the kd-tree path
         with pytest.raises(ValueError, match="NaN coordinates"):
             pcu.DatasetIndex(rb)
-    for a, b in ((q[:60000], ok), (ok, r), (ok[:300], r[:2000])):
-        for fn in (pcu.chamfer_distance, pcu.hausdorff_distance, pcu.one_sided_hausdorff_distance,
-                   lambda x, y: pcu.chamfer_distance(x, y, return_index=True), lambda x, y: pcu.chamfer_distance(x, y, p_norm=1)):
+    # the metrics: a cloud that is searched IN must survive the reference's kd-tree (everything else: test_nonfinite_metrics)
+    xb = ok.copy(); xb[17, 2] = np.nan
+    for a, b in ((ok, xb), (ok[:300], xb[:2000])):
+        for fn in (pcu.hausdorff_distance, pcu.one_sided_hausdorff_distance, lambda x, y: pcu.hausdorff_distance(y, x),
+                   lambda x, y: pcu.chamfer_distance(x, y, return_index=True), lambda x, y: pcu.chamfer_distance(y, x, p_norm=0)):
             with pytest.raises(ValueError, match="non-finite"):
                 fn(a, b)
     # the context is as good as new afterwards
@@ -530,6 +532,102 @@ def test_nonfinite_inputs(pcu, oracle_kind, dtype):
     d0, c0 = oracle.k_nearest_neighbors(ok, ok[:40000], 1, kind=oracle_kind)
     assert np.array_equal(c, c0) and np.array_equal(d, d0)
     assert float(pcu.chamfer_distance(ok, ok[:40000])) > 0
+
+
+def _same(a, b):
+    """tuples / scalars equal, NaN == NaN"""
+    a, b = np.atleast_1d(np.asarray(a, np.float64)), np.atleast_1d(np.asarray(b, np.float64))
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def _close(v, v0, rtol):
+    v, v0 = float(v), float(v0)
+    if np.isnan(v0) or np.isinf(v0):
+        return _same(v, v0)
+    return abs(v - v0) <= rtol * abs(v0)
+
+
+P_NORMS = (2, 1, np.inf, -np.inf, 0, 3)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_golden_nonfinite_metrics(pcu, tag):
+    """tests/golden/nf_*_metrics.npz (from the reference's own nanoflann + its Python tails): rows of a source / query cloud with a
+    non-finite coordinate take part exactly as src/point_cloud_distance.cpp:90-93,223 and __init__.py:112-115 make them -- -1.0 never
+    wins Hausdorff's max, Chamfer gathers through index -1 (numpy's last row) and carries inf / NaN into the mean; a NaN row makes
+    Chamfer's value NaN."""
+    g = np.load(os.path.join(GOLD, f"nf_{tag}_metrics.npz"))
+    rtol = 1e-4 if tag == "f32" else 1e-6
+    for name in ("inf", "mixed", "last"):
+        x, y = g[f"{name}_x"], g[f"{name}_y"]
+        assert _same(pcu.one_sided_hausdorff_distance(x, y), g[f"{name}_os_xy"]), name
+        assert _same(pcu.one_sided_hausdorff_distance(y, x), g[f"{name}_os_yx"]), name
+        assert _same(pcu.one_sided_hausdorff_distance(x, y, squared_distances=True), g[f"{name}_os_xy_sq"]), name
+        assert _same(pcu.hausdorff_distance(x, y, return_index=True), g[f"{name}_h"]), name
+        assert _same(pcu.hausdorff_distance(y, x, return_index=True), g[f"{name}_h_rev"]), name
+        ch, cxy, cyx = pcu.chamfer_distance(x, y, return_index=True)
+        assert np.array_equal(cxy, g[f"{name}_cxy"]) and np.array_equal(cyx, g[f"{name}_cyx"]) and (cxy == -1).sum() >= 4
+        assert _close(ch, g[f"{name}_ch"][0], rtol)
+        for j, p in enumerate(P_NORMS):
+            assert _close(pcu.chamfer_distance(x, y, p_norm=p), g[f"{name}_ch"][j], rtol), (name, p)
+            assert _close(pcu.chamfer_distance(y, x, p_norm=p), g[f"{name}_ch_rev"][j], rtol), (name, p)
+    x, y = g["nan_x"], g["nan_y"]
+    assert _same(pcu.one_sided_hausdorff_distance(x, y), g["nan_os_xy"])
+    for p in (2, 1, np.inf, -np.inf, 3):
+        assert np.isnan(pcu.chamfer_distance(x, y, p_norm=p)) and np.isnan(pcu.chamfer_distance(y, x, p_norm=p))
+    assert type(pcu.chamfer_distance(x, y)) == x.dtype.type
+    for fn in (lambda: pcu.one_sided_hausdorff_distance(y, x), lambda: pcu.hausdorff_distance(x, y), lambda: pcu.chamfer_distance(x, y, p_norm=0),
+               lambda: pcu.chamfer_distance(x, y, return_index=True)):
+        with pytest.raises(ValueError, match="non-finite"):
+            fn()
+    bad = np.full((12, 3), np.nan, x.dtype); bad[3] = np.inf
+    assert _same(pcu.one_sided_hausdorff_distance(bad, y), g["allbad_os"]) and tuple(g["allbad_os"]) == (-1.0, 0.0, -1.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_nonfinite_metrics(pcu, oracle_kind, dtype):
+    """The same at sizes that take the lane-per-query kernels (first the fused attempt, which refuses, then the row-based path), device
+    tensors included, against the oracle on the same arrays."""
+    import warnings
+    rng = np.random.default_rng(91)
+    rtol = 1e-4 if dtype == np.float32 else 1e-6
+    n, m = 70_000, 50_000
+    x = rng.random((n, 3)).astype(dtype); y = rng.random((m, 3)).astype(dtype)
+    xi = x.copy()
+    xi[rng.integers(0, n, 30), rng.integers(0, 2, 30)] = np.inf          # (+inf on axes 0 / 1, -inf on axis 2: one sign per axis)
+    xi[rng.integers(0, n, 10), 2] = -np.inf
+    xn = xi.copy(); xn[rng.integers(0, n, 20), rng.integers(0, 3, 20)] = np.nan
+    yl = y.copy(); yl[-1, 1] = np.inf
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for a, b in ((xi, y), (xi, yl), (y, xi)):
+            assert pcu.one_sided_hausdorff_distance(a, b) == oracle.one_sided_hausdorff_distance(a, b, kind=oracle_kind)
+            assert pcu.one_sided_hausdorff_distance(a, b, squared_distances=True) == oracle.one_sided_hausdorff_distance(a, b, squared_distances=True, kind=oracle_kind)
+            assert pcu.hausdorff_distance(a, b, return_index=True) == oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind)
+            ch, cxy, cyx = pcu.chamfer_distance(a, b, return_index=True)
+            ch0, cxy0, cyx0 = oracle.chamfer_distance(a, b, return_index=True, kind=oracle_kind)
+            assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and _close(ch, ch0, rtol)
+            for p in P_NORMS:
+                assert _close(pcu.chamfer_distance(a, b, p_norm=p), oracle.chamfer_distance(a, b, p_norm=p, kind=oracle_kind), rtol), p
+        assert pcu.one_sided_hausdorff_distance(xn, y) == oracle.one_sided_hausdorff_distance(xn, y, kind=oracle_kind)
+        assert np.isnan(pcu.chamfer_distance(xn, y)) and np.isnan(pcu.chamfer_distance(y, xn, p_norm=1))
+        with pytest.raises(ValueError, match="non-finite"):
+            pcu.hausdorff_distance(xn, y)
+        import torch
+        tx, ty = torch.from_numpy(xi).cuda(), torch.from_numpy(y).cuda()
+        assert pcu.hausdorff_distance(tx, ty, return_index=True) == oracle.hausdorff_distance(xi, y, return_index=True, kind=oracle_kind)
+        assert _close(pcu.chamfer_distance(tx, ty), oracle.chamfer_distance(xi, y, kind=oracle_kind), rtol)
+        from point_cloud_utils_amd import batched
+        pairs = ((xi, y), (x, y), (xi, yl), (y, xi))
+        res = batched.batched_hausdorff(lambda p: pairs[p], len(pairs))
+        for r_, (a, b) in zip(res, pairs):
+            assert tuple(r_) == oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind)
+        resc = batched.batched_chamfer(lambda p: pairs[p], len(pairs))
+        for v, (a, b) in zip(resc, pairs):
+            assert _close(v, oracle.chamfer_distance(a, b, kind=oracle_kind), rtol)
+    # finite clouds afterwards: the fused path again
+    assert _close(pcu.chamfer_distance(x, y), oracle.chamfer_distance(x, y, kind=oracle_kind), rtol)
+    assert pcu.last_stats()["n_passes"] > 0
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

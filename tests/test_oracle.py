@@ -59,6 +59,27 @@ def test_metrics_golden():
         assert np.array_equal(cxy, g[f"cxy_{tag}"]) and np.array_equal(cyx, g[f"cyx_{tag}"])
 
 
+def test_nonfinite_metrics_golden():
+    """tests/golden/nf_*_metrics.npz (generated from the reference's own nanoflann): the C port and the restated Python tails give the
+    same answers on clouds with non-finite rows -- unmatched source rows are -1 / -1.0, Chamfer gathers through index -1."""
+    import warnings
+    for tag in ("f32", "f64"):
+        g = np.load(os.path.join(GOLD, f"nf_{tag}_metrics.npz"))
+        same = lambda a, b: np.array_equal(np.asarray(a, np.float64), np.asarray(b, np.float64), equal_nan=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for name in ("inf", "mixed", "last"):
+                x, y = g[f"{name}_x"], g[f"{name}_y"]
+                assert same(oracle.one_sided_hausdorff_distance(x, y, kind="port"), g[f"{name}_os_xy"])
+                assert same(oracle.one_sided_hausdorff_distance(y, x, kind="port"), g[f"{name}_os_yx"])
+                assert same(oracle.hausdorff_distance(x, y, True, kind="port"), g[f"{name}_h"])
+                ch, cxy, cyx = oracle.chamfer_distance(x, y, return_index=True, kind="port")
+                assert np.array_equal(cxy, g[f"{name}_cxy"]) and np.array_equal(cyx, g[f"{name}_cyx"])
+                assert same([oracle.chamfer_distance(x, y, p_norm=p, kind="port") for p in (2, 1, np.inf, -np.inf, 0, 3)], g[f"{name}_ch"])
+            assert same(oracle.one_sided_hausdorff_distance(g["nan_x"], g["nan_y"], kind="port"), g["nan_os_xy"])
+            assert np.isnan(oracle.chamfer_distance(g["nan_x"], g["nan_y"], kind="port"))
+
+
 def test_reference_test_knn_body_on_oracle():
     """tests/test_examples.py:349-396 of the reference, with the oracle standing in for pcu."""
     rng = np.random.default_rng(0)
