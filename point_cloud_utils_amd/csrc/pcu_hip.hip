@@ -47,6 +47,27 @@ static int fail(int code, const char* fmt, ...) {
     do { hipError_t e_ = (x); if (e_ != hipSuccess)                                             \
         return fail(PCU_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// Host-side profile of a call (PCU_HIP_HOST_PROF=1; diagnostics): wall-clock marks at entry, first launch, last launch, result seen, exit;
+// the mean spans of every 1000 calls go to stderr. Tells the Python wrapper's share of a step from the library's (scratch/hostgap.py).
+struct HostProf {
+    bool on = getenv("PCU_HIP_HOST_PROF") != nullptr;
+    std::chrono::steady_clock::time_point t[6]; double acc[6] = {0, 0, 0, 0, 0, 0}; long n = 0; bool have_prev = false;
+    void mark(int i) { if (on) t[i] = std::chrono::steady_clock::now(); }
+    void done() {
+        if (!on) return;
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        if (have_prev) acc[0] += us(t[5], t[0]);          // previous exit -> this entry: the caller (Python wrapper, loop)
+        for (int i = 1; i < 5; ++i) acc[i] += us(t[i - 1], t[i]);
+        t[5] = t[4]; have_prev = true;
+        if (++n % 1000 == 0) {
+            fprintf(stderr, "[host prof] per call, us: caller %.2f | entry->first launch %.2f | enqueue %.2f | wait for result %.2f | exit %.2f\n",
+                    acc[0] / 999.0 * (999.0 / 1000.0), acc[1] / 1000, acc[2] / 1000, acc[3] / 1000, acc[4] / 1000);
+            for (double& a : acc) a = 0;
+        }
+    }
+};
+static HostProf g_hprof;
+
 // ------------------------------------------------------------------------------------------------ context
 struct pcu_hip_ctx {
     int device = 0;
@@ -1468,6 +1489,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
         t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;
     }
     tm.mark(0);
+    g_hprof.mark(1);
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
     if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1;
@@ -1733,6 +1755,7 @@ static int pcode_of(double p) {
 template <typename T>
 static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int64_t ny, double p_norm, int max_leaf,
                          int64_t* out_cxy, int64_t* out_cyx, unsigned flags, void* stream, pcu_hip_stats* st, PendingPair<T>& pp) {
+    g_hprof.mark(0);
     if (!c) return fail(PCU_HIP_ERR_INVALID, "null context");
     if (validate_sizes(nx, ny, "query_points", "dataset_points")) return PCU_HIP_ERR_INVALID;
     if (isnan(p_norm)) return fail(PCU_HIP_ERR_INVALID, "p_norm is NaN");
@@ -1754,6 +1777,7 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     // p = 2 without indices: the value is the sum of the nearest-neighbour distances -> fused epilogue, no result rows
     const int fuse = (p_norm == 2.0 && !out_cxy && !out_cyx) ? FUSE_SUM : FUSE_NONE;
     int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ_x, occ_y, out_cxy != nullptr, out_cyx != nullptr, pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
+    g_hprof.mark(2);
     if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     return 0;
 }
@@ -1781,6 +1805,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
         if (P.fuse) {
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
+            g_hprof.mark(3);
             memcpy(&host, c->h_pinned, sizeof host);
             if (pair_refused_nonfinite(P, host)) {          // non-finite coordinates: see below (nan_rule) and hausdorff_end
                 int nf[2];
@@ -1834,6 +1859,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
     } while (0);
     if (!rc && nan_result) { out_mean2[0] = out_mean2[1] = std::numeric_limits<double>::quiet_NaN(); if (st) st->n_queries = nx + ny; }
     ctx_end(c);
+    g_hprof.mark(4); g_hprof.done();
     if (rc == PCU_RETRY) return PCU_RETRY;
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }

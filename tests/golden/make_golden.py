@@ -77,7 +77,7 @@ def nonfinite_metric_cases(rng):
         out = {}
         x = rng.random((900, 3), dtype=dt); y = rng.random((700, 3), dtype=dt)
         xi = x.copy(); xi[5, 0] = np.inf; xi[100, 1] = np.inf; xi[899, 2] = np.inf; xi[40] = np.inf
-        xm = xi.copy(); xm[9, 2] = -np.inf; xm[10, 2] = -np.inf
+        xm = x.copy(); xm[5, 0] = np.inf; xm[77, 0] = np.inf; xm[9, 1] = -np.inf; xm[10, 1] = -np.inf; xm[899, 2] = np.inf; xm[40] = [np.inf, -np.inf, np.inf]      # one sign per axis
         yl = y.copy(); yl[-1, 0] = np.inf
         xn = x.copy(); xn[7, 1] = np.nan; xn[50] = np.nan; xn[51, 0] = np.inf
         for name, a, b in (("inf", xi, y), ("mixed", xm, y), ("last", xi, yl)):
