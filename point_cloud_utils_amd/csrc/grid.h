@@ -218,6 +218,54 @@ __global__ __launch_bounds__(kBlock) void k_bbox_partial(const BboxSide<T> a0, c
     bbox_body<T>(a.pts, a.n, a.partial, a.counts, a.n_counts, a.zero2, a.n_zero2, bid, second ? (int)gridDim.x - nb0 : nb0);
 }
 
+// The range [rlo, rhi] per axis -> a grid: cubic cells of edge h with about `occupancy` points per cell if the cloud filled the range
+// uniformly, capped at max_cells; axes with (near-)zero extent get one cell. Serial (one thread). Writes h, inv_h, G, ncells, slack, org, closed.
+template <typename T>
+__device__ __forceinline__ void grid_layout(GridParams<T>* gp, const T (&rlo)[3], const T (&rhi)[3], int n, double occupancy, int max_cells, double h_want) {
+    double ext[3];
+    for (int j = 0; j < 3; ++j) ext[j] = (double)rhi[j] - (double)rlo[j];
+    double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
+    double want = (double)n / (occupancy > 0 ? occupancy : 1.0);
+    if (want > (double)max_cells) want = (double)max_cells;
+    if (want < 1.0) want = 1.0;
+    int G[3] = {1, 1, 1};
+    double h = 1.0;
+    if (emax > 0 && isfinite(emax)) {
+        // active axes: extent not negligible against the largest one
+        bool act[3]; int nd = 0; double vol = 1.0;
+        for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
+        // (single precision for the root: this runs serially on one thread and any h near the target will do -- the grid only decides which
+        // candidates a query looks at; every block of a one-pass build computes the same value from the same inputs)
+        const float ratio = (float)vol / (float)want;
+        h = (double)(nd == 3 ? cbrtf(ratio) : (nd == 2 ? sqrtf(ratio) : ratio));
+        if (!(h > 0.0) || !isfinite(h)) h = pow(vol / want, 1.0 / nd);          // (ratio outside the float range)
+        if (h_want > 0 && h_want > h) h = h_want;             // fixed-radius searches (normals.h): cells no smaller than asked for
+        for (int it = 0; it < 400; ++it) {
+            double cells = 1.0;
+            const double inv_hd = 1.0 / h;                   // (a cell count one off at an exact multiple is harmless: cell_coord clamps)
+            for (int j = 0; j < 3; ++j) {
+                double g = act[j] ? floor(ext[j] * inv_hd) + 1.0 : 1.0;
+                if (g > 2048.0) g = 2048.0;                    // keeps row tables and int math small
+                G[j] = (int)g; cells *= g;
+            }
+            if (cells <= (double)max_cells) break;
+            h *= 1.05;
+        }
+        // a capped axis (2048) must still span its extent
+        for (int j = 0; j < 3; ++j) if (act[j] && h * G[j] < ext[j]) h = ext[j] / G[j] * 1.0000001;
+    }
+    gp->h = (T)h;
+    gp->inv_h = (T)1 / gp->h;
+    for (int j = 0; j < 3; ++j) {
+        gp->G[j] = G[j];
+        double scale = fabs((double)rlo[j]) + fabs((double)rhi[j]) + (double)G[j] * h;
+        gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
+    }
+    gp->ncells = G[0] * G[1] * G[2];
+    for (int j = 0; j < 3; ++j) gp->org[j] = rlo[j];
+    gp->closed = 0;
+}
+
 // One block folds the bbox partials; one thread then turns the bbox into a grid: cubic cells of edge h with about `occupancy` points per cell if the
 // cloud filled its bbox uniformly, capped at max_cells. Axes with (near-)zero extent get one cell.
 // NT = threads of the calling block. `gp` may be a block's private copy in LDS (k_bucket_onepass: every block lays out the grid itself,
@@ -274,7 +322,7 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
         gp->nonfinite = ((m & 1u) ? kNfNaN : 0) | ((pinf & ninf) ? kNfBothInf : 0) | ((pinf | ninf) ? kNfAnyInf : 0) | (int)(m << 8);      // (bits 8..14: the raw mask, for the kd-tree's root box)
     }
     if (sentinel) put_sentinels(sentinel - n, n);
-    double ext[3], mom[7] = {0, 0, 0, 0, 0, 0, 0};
+    double mom[7] = {0, 0, 0, 0, 0, 0, 0};
     T rlo[3], rhi[3];                               // the range the grid is laid over (see kCoreSigmas)
     for (int w = 0; w < nw; ++w) for (int q = 0; q < 7; ++q) mom[q] += s_mom[w][q];
     const double inv0 = mom[0] > 0 ? 1.0 / mom[0] : 0.0;
@@ -293,48 +341,8 @@ __device__ __forceinline__ void make_grid_body(GridParams<T>* gp, const T* __res
                 if (b < rhi[j] && b > rlo[j]) rhi[j] = b;
             }
         }
-        ext[j] = (double)rhi[j] - (double)rlo[j];
     }
-    double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
-    double want = (double)n / (occupancy > 0 ? occupancy : 1.0);
-    if (want > (double)max_cells) want = (double)max_cells;
-    if (want < 1.0) want = 1.0;
-    int G[3] = {1, 1, 1};
-    double h = 1.0;
-    if (emax > 0 && isfinite(emax)) {
-        // active axes: extent not negligible against the largest one
-        bool act[3]; int nd = 0; double vol = 1.0;
-        for (int j = 0; j < 3; ++j) { act[j] = ext[j] > emax * 1e-6; if (act[j]) { ++nd; vol *= ext[j]; } }
-        // (single precision for the root: this runs serially on one thread and any h near the target will do -- the grid only decides which
-        // candidates a query looks at; every block of a one-pass build computes the same value from the same inputs)
-        const float ratio = (float)vol / (float)want;
-        h = (double)(nd == 3 ? cbrtf(ratio) : (nd == 2 ? sqrtf(ratio) : ratio));
-        if (!(h > 0.0) || !isfinite(h)) h = pow(vol / want, 1.0 / nd);          // (ratio outside the float range)
-        if (h_want > 0 && h_want > h) h = h_want;             // fixed-radius searches (normals.h): cells no smaller than asked for
-        for (int it = 0; it < 400; ++it) {
-            double cells = 1.0;
-            const double inv_hd = 1.0 / h;                   // (a cell count one off at an exact multiple is harmless: cell_coord clamps)
-            for (int j = 0; j < 3; ++j) {
-                double g = act[j] ? floor(ext[j] * inv_hd) + 1.0 : 1.0;
-                if (g > 2048.0) g = 2048.0;                    // keeps row tables and int math small
-                G[j] = (int)g; cells *= g;
-            }
-            if (cells <= (double)max_cells) break;
-            h *= 1.05;
-        }
-        // a capped axis (2048) must still span its extent
-        for (int j = 0; j < 3; ++j) if (act[j] && h * G[j] < ext[j]) h = ext[j] / G[j] * 1.0000001;
-    }
-    gp->h = (T)h;
-    gp->inv_h = (T)1 / gp->h;
-    for (int j = 0; j < 3; ++j) {
-        gp->G[j] = G[j];
-        double scale = fabs((double)rlo[j]) + fabs((double)rhi[j]) + (double)G[j] * h;
-        gp->slack[j] = (T)(8.0 * (double)Limits<T>::eps * scale);
-    }
-    gp->ncells = G[0] * G[1] * G[2];
-    for (int j = 0; j < 3; ++j) gp->org[j] = rlo[j];
-    gp->closed = 0;
+    grid_layout<T>(gp, rlo, rhi, n, occupancy, max_cells, h_want);
     if (accumulators) { gp->sumsq = 0ull; gp->has_large = 0; }
 }
 template <typename T>
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const BucketSide<T
                         a.large_list, a.n_large, prof, cnt_cap, a.cap, a.bucket_total, a.n);
 }
 template <typename T>
-static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + (size_t)kStageRecs * sizeof(Pt4<T>); }
+static size_t bucket_sort_lds_bytes(int cnt_cap) { return (size_t)cnt_cap * 4 + (size_t)kStageRecs * sizeof(Pt4<T>) + 64; }      // (+ 64: grid2.h's packed stage starts up to 16 bytes in)
 
 
 template <typename T>

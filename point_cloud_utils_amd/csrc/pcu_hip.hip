@@ -20,6 +20,7 @@
 
 #include "../../include/pcu_hip.h"
 #include "grid.h"
+#include "grid2.h"
 #include "reduce.h"
 #include "search.h"
 namespace pcu {          // the k > 1 search kernels are compiled in search_kernels.hip (second translation unit, built in parallel)
@@ -109,6 +110,8 @@ struct pcu_hip_ctx {
     bool two_pass = false;                    // sticky: a one-pass index build of this context overflowed a bucket slot (grid.h: k_bucket_onepass)
     bool eager_large = false;                 // sticky: this context has met clouds with over-full buckets (surfaces, clusters): launch their
                                               // placement (k_bucket_large) with every build instead of on demand
+    unsigned long long* fill2 = nullptr; int fill_parity = 0;   // grid2.h "no memset": two sets of kFillWords bucket fill words; a one-pass build uses set
+                                                                 // fill_parity -- left zeroed by its predecessor -- and zeroes the other one for its successor
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 3;   // (measured on 262k-point pairs: 1 / 2 / 3 / 4 / 8 lanes = 106 / 66 / 54 / 64 / 67 us per pair: the host enqueue is the limit from 3 on)
@@ -224,6 +227,9 @@ struct GridIndex {
     double h_want = 0.0;                  // > 0: cells at least this large (fixed-radius searches)
     Pt4<T>* tmp = nullptr; unsigned *bucket_total = nullptr, *bucket_start = nullptr, *block_base = nullptr, *large_list = nullptr, *n_large = nullptr;
     bool one_pass = false;                // build with k_bucket_onepass (tmp holds nb_max slots of kLargeBucket records); cleared after an overflow
+    T* xpartial = nullptr;                // one-pass build, second form (grid2.h): the scatter blocks' bbox partials
+    bool lean = false;                    // the Pt4 records of `sorted` are not written (grid2.h: fused k = 1 calls read the coordinate + row-id streams only);
+                                          // make_pt4() fills them in when some other kernel needs them
     const T* src = nullptr; double occ_built = 0.0;       // what the index was built from (rebuild after an overflow)
 };
 
@@ -260,7 +266,8 @@ static size_t index_bytes(int64_t n, double occ) {
     int sh = 0, nb = 0;
     if (bucket_plan(n, occ, &sh, &nb))
         b += align_up(std::max((size_t)n, (size_t)nb * kLargeBucket) * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
-             align_up((size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * nb * 4, 256);
+             align_up((size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * nb * 4, 256) +
+             align_up((size_t)((n + 4095) / 4096) * kXPartStride * sizeof(T), 256);
     return b;
 }
 template <typename T>
@@ -281,6 +288,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
         if (aalloc(a, &g.tmp, one_pass ? std::max((size_t)n, (size_t)g.nb_max * kLargeBucket) : (size_t)n)) return -1;
         if (aalloc(a, &g.bucket_start, (size_t)g.nb_max + 1) || aalloc(a, &g.large_list, (size_t)g.nb_max + 1)) return -1;
         if (aalloc(a, &g.block_base, (size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * g.nb_max)) return -1;
+        if (one_pass && aalloc(a, &g.xpartial, (size_t)((n + 4095) / 4096) * kXPartStride)) return -1;
         g.pos_of = want_pos ? g.cell_of : nullptr;      // cell_of is not used by this build
     } else {
         g.pos_of = g.rank;                              // k_scatter turns rank into the slot, in place
@@ -310,7 +318,7 @@ static BucketSide<T> bucket_side(const GridIndex<T>& g, const T* pts) {
 }
 template <typename T>
 static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex<T>* b, const T* pb, double occb, hipStream_t s,
-                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, unsigned* tickets = nullptr) {
+                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, pcu_hip_ctx* ctx = nullptr) {
     a.src = pa; a.occ_built = occa;
     if (b) { b->src = pb; b->occ_built = occb; }
     // one launch set serves both clouds only if they are built the same way
@@ -322,6 +330,54 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     // round 2: 16.7 us against 8.1 + 4.9 us for the two launches; removed.)
     static const bool grid_kernel = getenv("PCU_HIP_GRID_KERNEL") != nullptr;          // (always the separate k_make_grid launch)
     const bool grid_in_onepass = !grid_kernel && a.bucketed && a.one_pass && (!b || (b->bucketed && b->one_pass));
+    // The one-pass build's second form (grid2.h): k_bucket_onepass3 -> k_bucket_sort2, while the bucket tables fit beside the scatter's stage.
+    // PCU_HIP_BUILD_V1=1 (and the diagnostics of the first form, PCU_HIP_GRID_KERNEL / PCU_HIP_PROF_BUILD) keep the round-3 chain below.
+    static const bool build_v1 = getenv("PCU_HIP_BUILD_V1") != nullptr || getenv("PCU_HIP_PROF_BUILD") != nullptr;
+    if (grid_in_onepass && !build_v1 && ctx && ctx->fill2 && a.xpartial && (!b || b->xpartial) && a.nb_max <= kStagedMaxBuckets && (!b || b->nb_max <= kStagedMaxBuckets)) {
+        unsigned long long* const fw = ctx->fill2 + (size_t)ctx->fill_parity * kFillWords;
+        unsigned long long* const fw_next = ctx->fill2 + (size_t)(ctx->fill_parity ^ 1) * kFillWords;
+        ctx->fill_parity ^= 1;
+        const int bpts = kBkThreads * StagedPts<T>::n;
+        auto side = [&](const GridIndex<T>& g, const T* p, double occ, int k) {
+            return Build2Side<T>{p, g.n, g.gp, g.shift, occ, g.max_cells, g.h_want, fw + (size_t)k * kStagedMaxBuckets, fw + 2 * kStagedMaxBuckets + k,
+                                 g.tmp, kLargeBucket, g.xpartial, (g.n + bpts - 1) / bpts, g.cell_start, g.sorted, g.pos_of, g.lean ? 0 : 1, g.n_large,
+                                 k == 0 ? fw_next : nullptr, k == 0 ? kFillWords : 0, k == 0 ? (unsigned*)zero2 : nullptr, k == 0 ? n_zero2 : 0, nullptr};
+        };
+        Build2Side<T> s0 = side(a, pa, occa, 0), s1 = b ? side(*b, pb, occb, 1) : s0;
+        const int c0 = s0.n_xpart, c1 = b ? s1.n_xpart : 0;
+        static const bool do_prof2 = getenv("PCU_HIP_PROF_BUILD2") != nullptr;
+        static long long* prof2 = nullptr;
+        if (do_prof2) { if (!prof2) HIP_TRY(hipMalloc((void**)&prof2, 16 * sizeof(long long))); HIP_TRY(hipMemsetAsync(prof2, 0, 16 * sizeof(long long), s)); }
+        s0.prof = s1.prof = do_prof2 ? prof2 : nullptr;
+        static bool attr_set2[2] = {false, false};
+        if (!attr_set2[sizeof(T) == 4 ? 0 : 1]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>()));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
+            attr_set2[sizeof(T) == 4 ? 0 : 1] = true;
+        }
+        hipLaunchKernelGGL(k_bucket_onepass3<T>, dim3(c0 + c1), dim3(kBkThreads), onepass3_lds_bytes<T>(), s, s0, s1, c0);
+        if (do_prof2) {
+            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            const double nb = h[15] > 0 ? (double)h[15] * 100.0 : 100.0;
+            fprintf(stderr, "[onepass3 prof] blocks %lld | mean us per block: layout %.2f  points in %.2f  keys+ranks %.2f  scan+reservations %.2f  staging %.2f  run copies %.2f  drain %.2f\n",
+                    h[15], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb);
+        }
+        const int t0 = a.nb_max, t1 = b ? b->nb_max : 0;
+        const int cnt_cap = 1 << std::max(a.shift, b ? b->shift : 0);
+        if (do_prof2) { HIP_TRY(hipMemsetAsync(prof2, 0, 16 * sizeof(long long), s)); }
+        Build2Args<T> sa; sa.a[0] = s0; sa.a[1] = s1;
+        hipLaunchKernelGGL(k_bucket_sort2<T>, dim3(t0 + t1 + (b ? 2 : 1)), dim3(kSortThreads), bucket_sort_lds_bytes<T>(cnt_cap), s, sa, t0, t1, cnt_cap);
+        if (do_prof2) {
+            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            const double nb = h[7] > 0 ? (double)h[7] * 100.0 : 100.0;
+            fprintf(stderr, "[sort2 prof] blocks %lld | mean us per block: head %.2f  load+rank %.2f  scan %.2f  place %.2f  copies %.2f  drain %.2f\n",
+                    h[7], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    a.lean = false; if (b) b->lean = false;            // (every other build writes the Pt4 records)
     {
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2, a.gp};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0, b->gp} : s0;
@@ -393,8 +449,8 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
 }
 template <typename T>
 static int index_build(GridIndex<T>& g, const T* d_pts, double occ, hipStream_t s, bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0,
-                       unsigned* tickets = nullptr) {
-    return index_build_pair<T>(g, d_pts, occ, nullptr, nullptr, 0.0, s, defer_large, zero2, n_zero2, tickets);
+                       pcu_hip_ctx* ctx = nullptr) {
+    return index_build_pair<T>(g, d_pts, occ, nullptr, nullptr, 0.0, s, defer_large, zero2, n_zero2, ctx);
 }
 
 // Refitted grids for unbalanced clouds (grid.h): core range of the cloud by three zooming histogram rounds, then
@@ -586,7 +642,9 @@ template <typename T>
 static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) {
     SearchArgs<T> a;
     a.gp = ridx.gp; a.ref = ridx.sorted; a.cell_start = ridx.cell_start; a.qsorted = j.qidx.sorted; a.n_ref = (unsigned)ridx.n;
-    a.ref_xyz = xyz_of(ridx.sorted, ridx.n);
+    a.ref_xyz = xyz_of(ridx.sorted, ridx.n); a.ref_idx = idx32_of(ridx.sorted, ridx.n);
+    a.q_xyz = xyz_of(j.qidx.sorted, j.qidx.n); a.q_idx = idx32_of(j.qidx.sorted, j.qidx.n);
+    a.lean = (ridx.lean || j.qidx.lean) ? 1 : 0;
     a.qlist = nullptr; a.qcount_dev = nullptr; a.nq = 0; a.R = 1; a.kreq = j.k; a.squared = j.squared ? 1 : 0;
     a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0; a.row_out = j.row_out ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
@@ -1344,8 +1402,8 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         }
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
         tm.mark(0);
-        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/!c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break; }
-        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c->tickets))) break;
+        if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/!c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c))) break; }
+        else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c))) break;
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         const bool spec = kd_speculate_fork(c, s, job);
@@ -1488,11 +1546,19 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
         t.w_sums = (int)(offsetof(ResultBlock, sums) / 4); t.w_vals = (int)(offsetof(ResultBlock, vals) / 4);
         t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;
     }
+    // A fused attempt reads the clouds' coordinate + row-id streams only: its index build leaves the Pt4 records unwritten (grid2.h: 12 bytes per
+    // point less to write); whoever takes the call over when the attempt does not stand fills them in first (pair_unlean).
+    {
+        static const bool no_lean = getenv("PCU_HIP_NO_LEAN") != nullptr;
+        const bool lean = P.fuse != FUSE_NONE && !no_lean && ix.bucketed && iy.bucketed && ix.one_pass && iy.one_pass && !want_pos_x && !want_pos_y;
+        ix.lean = iy.lean = P.xy.qidx.lean = P.xy.ridx.lean = P.yx.qidx.lean = P.yx.ridx.lean = lean;
+    }
     tm.mark(0);
     g_hprof.mark(1);
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c->tickets)) return -1;
+    if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c)) return -1;
+    P.xy.qidx.lean = P.yx.ridx.lean = ix.lean; P.xy.ridx.lean = P.yx.qidx.lean = iy.lean;      // (the build says what it wrote)
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
     if (pair_search_enqueue(c, s, P, st)) return -1;
@@ -1560,6 +1626,18 @@ static int fused_continue(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>
     if (wait_result_block(c, s)) return -1;
     memcpy(&host, c->h_pinned, sizeof host);
     return fused_ok(P, host, tie_matters, /*stragglers_done=*/true) ? 1 : 0;
+}
+// The Pt4 records of a pair's lean indexes (grid2.h), for everything that is not the fused fast path.
+template <typename T>
+static int pair_unlean(hipStream_t s, PairState<T>& P) {
+    GridIndex<T>& ix = P.xy.qidx; GridIndex<T>& iy = P.xy.ridx;
+    if (!ix.lean && !iy.lean) return 0;
+    const Pt4Side<T> a{ix.sorted, ix.n}, b{iy.sorted, iy.n};
+    const int nb0 = ix.lean ? std::min((ix.n + 8 + kBlock - 1) / kBlock, 2048) : 0, nb1 = iy.lean ? std::min((iy.n + 8 + kBlock - 1) / kBlock, 2048) : 0;
+    hipLaunchKernelGGL(k_make_pt4<T>, dim3(nb0 + nb1), dim3(kBlock), 0, s, a, b, nb0);
+    HIP_TRY(hipGetLastError());
+    P.xy.qidx.lean = P.xy.ridx.lean = P.yx.qidx.lean = P.yx.ridx.lean = false;
+    return 0;
 }
 // A pass refused non-finite input (counter bit 4): the classification of both clouds (GridParams::nonfinite; [0] = x / source, [1] = y / target).
 template <typename T>
@@ -1675,12 +1753,13 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 int nf[2];
                 if ((rc = pair_nonfinite_flags(s, P, nf))) break;
                 if (!pair_nonfinite_ok(P, nf)) { rc = nonfinite_error(true); break; }
-                if ((rc = unfuse_and_research(c, s, P, st))) break;
+                if ((rc = pair_unlean(s, P)) || (rc = unfuse_and_research(c, s, P, st))) break;
             }
             else if (fused_ok(P, host, tie_matters)) {
                 for (int d = 0; d < (two_sided ? 2 : 1); ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = pair_unlean(s, P))) break;
             else if ((rc = fused_continue(c, ar, s, P, st, host, tie_matters)) != 0) { if (rc < 0) break; rc = 0; done = true; }
             else { skewed = skewed_everywhere(P, host); if ((rc = unfuse_and_research(c, s, P, st, skewed))) break; }
         }
@@ -1811,12 +1890,13 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 int nf[2];
                 if ((rc = pair_nonfinite_flags(s, P, nf))) break;
                 if (!pair_nonfinite_ok(P, nf)) { if (nan_rule(nf)) { rc = 0; nan_result = true; } else rc = nonfinite_error(true); break; }
-                if ((rc = unfuse_and_research(c, s, P, st))) break;
+                if ((rc = pair_unlean(s, P)) || (rc = unfuse_and_research(c, s, P, st))) break;
             }
             else if (fused_ok(P, host, false)) {
                 for (int d = 0; d < 2; ++d) if (st) { st->n_escalated += host.counters[d][C_U1]; st->n_tie_flagged += host.counters[d][C_T1]; }
                 done = true;
             } else if (fused_rescale(c, s, P, host)) { rc = PCU_RETRY; break; }
+            else if ((rc = pair_unlean(s, P))) break;
             else if ((rc = fused_continue(c, ar, s, P, st, host, false)) != 0) { if (rc < 0) break; rc = 0; done = true; }
             else { skewed = skewed_everywhere(P, host); if ((rc = unfuse_and_research(c, s, P, st, skewed))) break; }
         }
@@ -2146,6 +2226,8 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     memset(c->h_pinned, 0, 64 * sizeof(int));
     HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
     HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&c->fill2, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->fill2, 0, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
     *out_ctx = c;
     return 0;
 }
@@ -2159,6 +2241,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     if (c->aux) (void)hipFree(c->aux);
     if (c->tickets) (void)hipFree(c->tickets);
+    if (c->fill2) (void)hipFree(c->fill2);
     if (c->arena) (void)hipFree(c->arena);
     for (hipEvent_t e : {c->kd_spec.ev_fork, c->kd_spec.ev_init, c->kd_spec.ev_done}) if (e) (void)hipEventDestroy(e);
     kd_graph_drop(c);

@@ -21,26 +21,31 @@ template <> struct alignas(32) Pt4<double> { double x, y, z; long long idx; };
 
 // Coordinates-only copy of a cell-ordered cloud (3 T per record, no row id): the candidate stream of k_search1_flat (search.h,
 // PCU_FLAT_XYZ). It lives right behind the n + 8 Pt4 records (incl. the 8 +inf sentinels) of the same allocation and has 8 sentinel
-// records of its own.
+// records of its own. Behind it: the row ids of the same records as 32-bit integers (idx32_of; n + 8 of them). Every index build writes
+// both streams; a LEAN build (grid2.h: fused k = 1 calls, which never look at a Pt4 record) writes only them and leaves the Pt4 array
+// unwritten until some other kernel needs it (k_make_pt4).
 #ifndef PCU_FLAT_XYZ
 #define PCU_FLAT_XYZ 1
 #endif
 template <typename T> __host__ __device__ __forceinline__ T* xyz_of(Pt4<T>* sorted, int n) { return reinterpret_cast<T*>(sorted + n + 8); }
 template <typename T> __host__ __device__ __forceinline__ const T* xyz_of(const Pt4<T>* sorted, int n) { return reinterpret_cast<const T*>(sorted + n + 8); }
+template <typename T> __host__ __device__ __forceinline__ int* idx32_of(Pt4<T>* sorted, int n) { return reinterpret_cast<int*>(xyz_of(sorted, n) + 3 * (size_t)(n + 8)); }
+template <typename T> __host__ __device__ __forceinline__ const int* idx32_of(const Pt4<T>* sorted, int n) { return reinterpret_cast<const int*>(xyz_of(sorted, n) + 3 * (size_t)(n + 8)); }
 template <typename T> __device__ __forceinline__ void put_xyz(Pt4<T>* sorted, int n, unsigned pos, const Pt4<T>& r) {
 #if PCU_FLAT_XYZ
     T* o = xyz_of(sorted, n) + 3 * (size_t)pos;
     o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    idx32_of(sorted, n)[pos] = (int)r.idx;
 #endif
 }
-template <typename T> __device__ __forceinline__ void put_sentinels(Pt4<T>* sorted, int n) {       // records n..n+7 of both streams: see k_search / k_search1_flat
+template <typename T> __device__ __forceinline__ void put_sentinels(Pt4<T>* sorted, int n) {       // records n..n+7 of all streams: see k_search / k_search1_flat
     for (int j = 0; j < 8; ++j) {
         Pt4<T> s; s.x = s.y = s.z = (T)INFINITY; s.idx = 0x7fffffff;
         sorted[n + j] = s;
         put_xyz(sorted, n, (unsigned)(n + j), s);
     }
 }
-constexpr size_t sorted_records_bytes(size_t n, size_t rec_bytes, size_t scalar_bytes) { return (n + 8) * rec_bytes + (PCU_FLAT_XYZ ? (n + 8) * 3 * scalar_bytes : 0); }
+constexpr size_t sorted_records_bytes(size_t n, size_t rec_bytes, size_t scalar_bytes) { return (n + 8) * rec_bytes + (PCU_FLAT_XYZ ? (n + 8) * (3 * scalar_bytes + 4) : 0); }
 
 template <typename T> struct Limits;
 template <> struct Limits<float>  { static constexpr float  max_v = FLT_MAX; static constexpr float  eps = FLT_EPSILON; };

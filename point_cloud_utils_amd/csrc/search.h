@@ -37,6 +37,9 @@ struct SearchArgs {
     const T* ref_xyz;               // the same records without the row id (3 T each; GridIndex::xyz), k_search1_flat's candidate stream
     const unsigned* cell_start;     // [ncells+1]
     const Pt4<T>* qsorted;          // queries in their own cell order
+    const T* q_xyz; const int* q_idx;   // the same records as two streams (pcu_types.h: xyz_of / idx32_of): coordinates, 32-bit row ids ...
+    const int* ref_idx;             // ... and the dataset's row ids. k_search1_flat reads only the streams; with `lean` set the Pt4 arrays `ref` /
+    int lean;                       // `qsorted` are NOT written (grid2.h) and k_search_wave reads the streams too. No other kernel takes a lean index.
     const int* qlist;               // nullable: positions into qsorted to process (escalation / tie passes)
     const int* qcount_dev;          // nullable: device-side count for qlist passes
     int nq;                         // number of work items when qcount_dev is null
@@ -633,7 +636,13 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     if (t >= nq) return;
     constexpr bool valid = true;
     const int qpos = a.qlist ? a.qlist[t] : t;
-    const Pt4<T> q = a.qsorted[qpos];
+    Pt4<T> q;                                         // (from the coordinate stream; the row id only where an epilogue uses it)
+    {
+        struct __attribute__((packed, aligned(4))) Q3 { T v[3]; };
+        const Q3 c = *reinterpret_cast<const Q3*>(a.q_xyz + 3 * (size_t)qpos);
+        q.x = c.v[0]; q.y = c.v[1]; q.z = c.v[2];
+        q.idx = FUSE == FUSE_SUM ? 0 : a.q_idx[qpos];
+    }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
     const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
@@ -765,7 +774,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     };
     auto row_id = [&](unsigned rec_off) -> int {
         if (!XYZ) return (int)reinterpret_cast<const Pt4<T>*>(base + (size_t)rec_off)->idx;
-        return (int)a.ref[rec_off / kRec].idx;
+        return a.ref_idx[rec_off / kRec];
     };
     if (FUSE != FUSE_SUM && boff != 0xffffffffu) {        // (a fused sum needs neither the row id nor the tie flags)
         int hits; unsigned ro;
@@ -877,7 +886,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         const bool second = w >= nq1;
         int R = second ? a.R2 : a.R;
         const int qpos = second ? a.qlist2[w - nq1] : (a.qlist ? a.qlist[w] : w);
-        const Pt4<T> q = a.qsorted[qpos];
+        const bool lean = a.lean != 0;              // (uniform) records come as two streams instead of Pt4
+        auto rec_at = [&](const Pt4<T>* recs, const T* xyz, const int* ids, unsigned i) -> Pt4<T> {
+            if (!lean) return recs[i];
+            Pt4<T> r; r.x = xyz[3 * (size_t)i]; r.y = xyz[3 * (size_t)i + 1]; r.z = xyz[3 * (size_t)i + 2]; r.idx = ids[i];
+            return r;
+        };
+        const Pt4<T> q = rec_at(a.qsorted, a.q_xyz, a.q_idx, (unsigned)qpos);
         const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
         const T shrink = (T)1 - (T)4 * Limits<T>::eps;
 
@@ -979,7 +994,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 for (unsigned p = ls; p < (heavy ? ls : le); p += kU) {
                     Pt4<T> cc[kU];
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) cc[u] = a.ref[min(p + (unsigned)u, le - 1u)];
+                    for (int u = 0; u < kU; ++u) cc[u] = rec_at(a.ref, a.ref_xyz, a.ref_idx, min(p + (unsigned)u, le - 1u));
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
                         const Pt4<T>& c = cc[u];
@@ -1003,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                     for (unsigned p = hs + (unsigned)lane; p < he; p += 64u * kH) {
                         Pt4<T> hc[kH];
 #pragma unroll
-                        for (int u = 0; u < kH; ++u) hc[u] = a.ref[min(p + 64u * (unsigned)u, he - 1u)];
+                        for (int u = 0; u < kH; ++u) hc[u] = rec_at(a.ref, a.ref_xyz, a.ref_idx, min(p + 64u * (unsigned)u, he - 1u));
 #pragma unroll
                         for (int u = 0; u < kH; ++u) {
                             const Pt4<T>& c = hc[u];

@@ -1,7 +1,15 @@
+"""Per-kernel means of rocprofv3 --pmc csv output: pmc_sum.py <dir> [<dir> ...]  (FETCH_SIZE / WRITE_SIZE are printed in MB as reported;
+on gfx950 FETCH_SIZE counts half the bytes of wide reads -- profiles/r03_calib.txt)."""
 import csv, glob, sys, collections
-tag = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else "k_search1_flat"
-acc = collections.defaultdict(list)
-for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if pat in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in sorted(acc): print(f"{k:28s} n={len(acc[k]):3d} mean={sum(acc[k])/len(acc[k]):.4g}")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sys.argv[1:]:
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("void pcu::", "").split("(")[0]
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    parts = []
+    for c in sorted(acc[k]):
+        v = sum(acc[k][c]) / len(acc[k][c])
+        parts.append(f"{c}={v / 1024:.2f} MB" if c.endswith("_SIZE") else f"{c}={v:.4g}")
+    print(f"{k[:60]:60s} n={len(next(iter(acc[k].values()))):3d}  " + "  ".join(parts))
