@@ -1,0 +1,17 @@
+#!/bin/bash
+# SQ / TA counter passes of bench.py for one kernel name pattern: gpu_sq.sh <tag> <kernel pattern> [ENV=VALUE ...]
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
+TAG=${1:-p}; PAT=${2:-k_search1}; shift; shift
+for kv in "$@"; do export "$kv"; done
+ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
+pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
+pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pass sq2 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE
+pass ta TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
+pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS
+cd $ROOT
+python scratch/pmc_sum.py $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_sq2 $OUT/${TAG}_pmc_ta $OUT/${TAG}_pmc_lds | grep "$PAT" > $OUT/${TAG}_sq.txt
+rm -rf $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_sq2 $OUT/${TAG}_pmc_ta $OUT/${TAG}_pmc_lds
+cat $OUT/${TAG}_sq.txt
