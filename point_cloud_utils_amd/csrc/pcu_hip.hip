@@ -23,7 +23,6 @@
 #include "grid2.h"
 #include "reduce.h"
 #include "search.h"
-#include "search_tile.h"
 namespace pcu {          // the k > 1 search kernels are compiled in search_kernels.hip (second translation unit, built in parallel)
 #define PCU_SEARCH_INST extern template
 #include "search_inst.h"
@@ -62,8 +61,6 @@ struct HostProf {
         for (int i = 1; i < 5; ++i) acc[i] += us(t[i - 1], t[i]);
         t[5] = t[4]; have_prev = true;
         if (++n % 1000 == 0) {
-            unsigned long long hd[8]; if (hipMemcpyFromSymbol(hd, HIP_SYMBOL(pcu::g_tile_dbg), sizeof hd) == hipSuccess && hd[0])
-                fprintf(stderr, "[tile dbg] blocks %llu  mean T %.1f  fallbacks %llu  mean R %.2f  max T %llu  rows too many %llu\n", hd[0], (double)hd[1] / hd[0], hd[2], (double)hd[3] / hd[0], hd[4], hd[5]);
             fprintf(stderr, "[host prof] per call, us: caller %.2f | entry->first launch %.2f | enqueue %.2f | wait for result %.2f | exit %.2f\n",
                     acc[0] / 999.0 * (999.0 / 1000.0), acc[1] / 1000, acc[2] / 1000, acc[3] / 1000, acc[4] / 1000);
             for (double& a : acc) a = 0;
@@ -559,9 +556,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     if (K == 1 && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
         const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
-        static const bool tile = getenv("PCU_HIP_TILE") != nullptr;          // the LDS-staged variant (search_tile.h; A/B switch)
-#define PCU_FLAT(FUSE) do { if (tile) hipLaunchKernelGGL((k_search1_tile<T, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); \
-                            else hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0); } while (0)
+        // (An LDS-staged, block-cooperative variant of this pass -- the north-star's tile design -- was measured again in round 4: 243-593 us
+        // against 77 us, profiles/r04_flat_tile_ab.txt; removed.)
+#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
         else if (a.fuse == FUSE_ARGMAX) PCU_FLAT(FUSE_ARGMAX);
         else PCU_FLAT(FUSE_NONE);
