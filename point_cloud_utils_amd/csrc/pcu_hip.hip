@@ -1383,9 +1383,13 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         T* dd = out_d; long long* di = (long long*)out_i;
         if (!on_dev) { if ((rc = aalloc(ar, &dd, (size_t)nq * k))) break; if ((rc = aalloc(ar, &di, (size_t)nq * k))) break; }
         SearchJob<T> job;
-        // k >= 4: a result row is >= 48 bytes, so every kernel writes it straight to the query's original row and no
-        // row-order restore pass runs (k = 8, 1M queries: 52 us saved); smaller k: cell-ordered rows + k_unpermute
-        const bool row_out = k >= 4;
+        // Every kernel writes a result row straight to the query's ORIGINAL row: no cell-ordered copy, no row-order restore pass, no row -> slot
+        // table from the index build. For k >= 4 (rows >= 48 bytes) that was always so; for k < 4 the rows used to be written coalesced in the
+        // queries' cell order and gathered back by k_unpermute -- two scattered line fetches per query (185 MB for a 12 MB result at 1M, k = 1) plus
+        // 37 MB of scattered row -> slot stores in the build. The scattered 4 / 8-byte row stores cost 67 MB instead (profiles/r04_c2_ab.txt):
+        // config 2 0.184 -> 0.154 ms. PCU_HIP_ROW_OUT_MIN_K=4 restores the old split.
+        static const int row_out_min_k = getenv("PCU_HIP_ROW_OUT_MIN_K") ? atoi(getenv("PCU_HIP_ROW_OUT_MIN_K")) : 1;
+        const bool row_out = k >= row_out_min_k;
         job.row_out = row_out;
         if (pidx) job.ridx = index_grid<T>(pidx);
         else if ((rc = index_alloc(ar, job.ridx, nr, occ, false, true, use_one_pass(c)))) break;
