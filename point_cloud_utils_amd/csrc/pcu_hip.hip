@@ -1503,8 +1503,12 @@ static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, p
 }
 template <typename T>
 static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int64_t nx, const T* y, int64_t ny, bool on_dev,
-                      bool squared, double occ_x, double occ_y, bool want_pos_x, bool want_pos_y, PairState<T>& P, Timer& tm,
+                      bool squared, double occ_x, double occ_y, long long* ext_ixy, long long* ext_iyx, PairState<T>& P, Timer& tm,
                       pcu_hip_stats* st, bool two_sided, int max_leaf, bool tie_order_xy, bool tie_order_yx, int fuse_mode = FUSE_NONE) {
+    // (ext_ixy / ext_iyx: device arrays of the caller that take the correspondences directly. Result rows of the row-based path are in the
+    // caller's ROW order -- the search kernels write them there, see knn_attempt -- so no row -> slot table is built and no restore pass runs.)
+    constexpr bool want_pos_x = false, want_pos_y = false;
+    P.xy.row_out = P.yx.row_out = true;
     P.two = two_sided;
     P.xy.leaf_max = P.yx.leaf_max = max_leaf > 0 ? max_leaf : 10; P.xy.tie_order = tie_order_xy; P.yx.tie_order = tie_order_yx;
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
@@ -1526,7 +1530,8 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     P.rb = &P.cb->rb;
     if (scratch_alloc(ar, P.xy.sc, nx, P.rb->counters[0]) || scratch_alloc(ar, P.yx.sc, ny, P.rb->counters[1])) return -1;
     if (aalloc(ar, &P.xy.out_d, (size_t)nx) || aalloc(ar, &P.yx.out_d, (size_t)ny)) return -1;
-    if (aalloc(ar, &P.xy.out_i, (size_t)nx) || aalloc(ar, &P.yx.out_i, (size_t)ny)) return -1;
+    P.xy.out_i = ext_ixy; P.yx.out_i = ext_iyx;
+    if ((!P.xy.out_i && aalloc(ar, &P.xy.out_i, (size_t)nx)) || (!P.yx.out_i && aalloc(ar, &P.yx.out_i, (size_t)ny))) return -1;
     if (aalloc(ar, &P.pv, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pi, (size_t)2 * kRedBlocks) || aalloc(ar, &P.pd, (size_t)2 * kRedBlocks)) return -1;
     if (aalloc(ar, &P.tie_hit, 16)) return -1;
     P.res_v = reinterpret_cast<T*>(P.rb->vals); P.res_ij = P.rb->ij; P.res_s = P.rb->sums;
@@ -1699,7 +1704,7 @@ template <typename T>
 static int argmax_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, bool two_sided) {
     auto side = [&](const SearchJob<T>& j) {
         const int n = j.qidx.n;
-        return ArgmaxSide<T>{j.out_d, j.qidx.sorted, j.out_i, n, std::min((n + kBlock - 1) / kBlock, kRedBlocksFused)};
+        return ArgmaxSide<T>{j.out_d, j.row_out ? nullptr : j.qidx.sorted, j.out_i, n, std::min((n + kBlock - 1) / kBlock, kRedBlocksFused)};
     };
     const ArgmaxSide<T> a = side(P.xy);
     ArgmaxSide<T> b = a; b.n = 0; b.nb = 0;
@@ -1738,7 +1743,7 @@ static int hausdorff_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, i
     if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[pair begin] restarts=%d nx=%lld ny=%lld occ_x=%.3f occ_y=%.3f\n", pp.restarts, (long long)nx, (long long)ny, occ_x, occ_y);
     pp.ar = Arena{c}; pp.tm = Timer{c, s, st}; pp.s = s; pp.x = x; pp.y = y; pp.nx = nx; pp.ny = ny;
     pp.on_dev = on_dev; pp.squared = squared; pp.two_sided = two_sided; pp.flags = flags; pp.max_leaf = max_leaf; pp.st = st;
-    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ_x, occ_y, false, false, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, squared, occ_x, occ_y, nullptr, nullptr, pp.P, pp.tm, st, two_sided, max_leaf, false, false, FUSE_ARGMAX);
     if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     return 0;
 }
@@ -1861,7 +1866,8 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     const bool tie_xy = tie_any && (out_cxy != nullptr || p_norm != 2.0), tie_yx = tie_any && (out_cyx != nullptr || p_norm != 2.0);
     // p = 2 without indices: the value is the sum of the nearest-neighbour distances -> fused epilogue, no result rows
     const int fuse = (p_norm == 2.0 && !out_cxy && !out_cyx) ? FUSE_SUM : FUSE_NONE;
-    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ_x, occ_y, out_cxy != nullptr, out_cyx != nullptr, pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
+    int rc = pair_setup(c, pp.ar, s, x, nx, y, ny, on_dev, /*squared=*/false, occ_x, occ_y, on_dev ? (long long*)out_cxy : nullptr, on_dev ? (long long*)out_cyx : nullptr,
+                        pp.P, pp.tm, st, true, max_leaf, tie_xy, tie_yx, fuse);
     g_hprof.mark(2);
     if (rc) { ctx_end(c); return rc < 0 ? rc : PCU_HIP_ERR_RUNTIME; }
     return 0;
@@ -1907,23 +1913,16 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             else { skewed = skewed_everywhere(P, host); if ((rc = unfuse_and_research(c, s, P, st, skewed))) break; }
         }
         if (!done) {
-            long long* ext_xy = (on_dev && out_cxy) ? (long long*)out_cxy : nullptr;
-            long long* ext_yx = (on_dev && out_cyx) ? (long long*)out_cyx : nullptr;
-            // row-ordered correspondences: straight into the caller's device arrays, or via a staging buffer
-            long long *dst_xy = ext_xy, *dst_yx = ext_yx;
-            if (!on_dev && out_cxy && (rc = aalloc(ar, &dst_xy, (size_t)nx))) break;
-            if (!on_dev && out_cyx && (rc = aalloc(ar, &dst_yx, (size_t)ny))) break;
             const int pc = pcode_of(p_norm);
             // __init__.py:112: norm(x[corrs_y_to_x] - y).mean() -> queries y, targets x ; :113 the other way round
             const int nbx = std::min((int)((nx + kBlock - 1) / kBlock), kRedBlocksFused), nby = std::min((int)((ny + kBlock - 1) / kBlock), kRedBlocksFused);
             for (int attempt = 0; attempt < 2; ++attempt) {
                 const bool given = attempt == 0 && skewed;       // no searches were re-run: no epilogue to run either, straight to the refit path
                 if (given) { rc = pair_finish(c, ar, s, P, st, &host, true, true); if (rc == PCU_NONFINITE) { rc = refused(); break; } if (rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; continue; }
-                if (dst_xy && (rc = unpermute_enqueue<T>(s, P.xy, nullptr, dst_xy))) break;
-                if (dst_yx && (rc = unpermute_enqueue<T>(s, P.yx, nullptr, dst_yx))) break;
                 // both directions' norms + final sums + the copy of the result block to pinned host memory: one launch
-                const PnormSide<T> sx{P.xy.qidx.sorted, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx, P.xy.sc.counters + C_SKEW, (long long)ny},
-                                   sy{P.yx.qidx.sorted, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby, P.yx.sc.counters + C_SKEW, (long long)nx};
+                // (the rows are in the caller's row order: the queries are the clouds themselves)
+                const PnormSide<T> sx{nullptr, P.dx, P.dy, P.xy.out_i, P.xy.out_d, (int)nx, nbx, P.xy.sc.counters + C_SKEW, (long long)ny},
+                                   sy{nullptr, P.dy, P.dx, P.yx.out_i, P.yx.out_d, (int)ny, nby, P.yx.sc.counters + C_SKEW, (long long)nx};
                 hipLaunchKernelGGL(k_pnorm_pair<T>, dim3(nbx + nby), dim3(kBlock), 0, s, sx, sy, pc, p_norm, P.pd, P.res_s,
                                    reinterpret_cast<unsigned*>(P.rb->pad), reinterpret_cast<const int*>(P.rb), c->h_pinned, ++c->seq);
                 HIP_TRY(hipGetLastError());
@@ -1933,8 +1932,8 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             }
             if (rc || nan_result) break;
             if (!on_dev) {
-                if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, dst_xy, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
-                if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, dst_yx, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+                if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.xy.out_i, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+                if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.yx.out_i, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
             }
         }

@@ -26,7 +26,7 @@ __device__ __forceinline__ void argmax_combine(T& v, long long& i, T v2, long lo
 // partials, the last block to finish folds them, writes {value, i, j} per direction and copies the call's result
 // block to pinned host memory (see k_pnorm_pair).
 template <typename T>
-struct ArgmaxSide { const T* d; const Pt4<T>* qsorted; const long long* corr; int n; int nb; };
+struct ArgmaxSide { const T* d; const Pt4<T>* qsorted; const long long* corr; int n; int nb; };      // qsorted == nullptr: d / corr are in the caller's ROW order
 
 template <typename T>
 __device__ __forceinline__ void block_argmax(T& v, long long& idx) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_argmax_pair(const ArgmaxSide<T> s0, 
     const int bid = second ? (int)blockIdx.x - s0.nb : (int)blockIdx.x;
     T v = -Limits<T>::max_v; long long idx = 0x7fffffffffffffffll;
     for (int i = bid * kBlock + threadIdx.x; i < sd.n; i += sd.nb * kBlock)
-        argmax_combine(v, idx, sd.d[i], ((long long)sd.qsorted[i].idx << 32) | (long long)i);
+        argmax_combine(v, idx, sd.d[i], ((long long)(sd.qsorted ? (int)sd.qsorted[i].idx : i) << 32) | (long long)i);
     block_argmax(v, idx);
     __shared__ bool s_last;
     if (threadIdx.x == 0) {
@@ -291,7 +291,9 @@ enum { P_TWO = 0, P_ONE = 1, P_INF = 2, P_NINF = 3, P_ZERO = 4, P_GEN = 5 };
 // both searches + these sums) into pinned host memory, so the call needs no separate final-sum launches and no
 // device-to-host copy kernel behind them.
 template <typename T>
-struct PnormSide { const Pt4<T>* qsorted; const T* tgt; const long long* corr; const T* d; int n; int nb;
+struct PnormSide { const Pt4<T>* qsorted;     // the queries in the order of corr / d: their cell order -- or nullptr: corr / d are in the caller's ROW order, the queries are qpts
+                   const T* qpts;
+                   const T* tgt; const long long* corr; const T* d; int n; int nb;
                    const int* giveup;         // the direction's skew / unplaced-buckets flags: no rows exist (yet) when one is set
                    long long n_tgt; };        // rows of tgt: a correspondence outside [0, n_tgt) is an unwritten row (a straggler whose
                                               // result comes with the host-driven passes; this launch is then repeated) and is not followed
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(kBlock) void k_pnorm_pair(const PnormSide<T> s0, co
         long long c = sd.corr[i];
         if (c == -1ll) c = sd.n_tgt - 1;
         if ((unsigned long long)c >= (unsigned long long)sd.n_tgt) c = 0;          // (see PnormSide::n_tgt)
-        const Pt4<T> q = sd.qsorted[i];
+        Pt4<T> q;
+        if (sd.qsorted) q = sd.qsorted[i]; else { q.x = sd.qpts[3 * (size_t)i]; q.y = sd.qpts[3 * (size_t)i + 1]; q.z = sd.qpts[3 * (size_t)i + 2]; }
         const T a = sd.tgt[3 * c] - q.x, b = sd.tgt[3 * c + 1] - q.y, e = sd.tgt[3 * c + 2] - q.z;
         const T aa = a < 0 ? -a : a, ab = b < 0 ? -b : b, ae = e < 0 ? -e : e;
         const bool any_nan = a != a || b != b || e != e;
