@@ -99,6 +99,13 @@ def cpu_baseline(x, y, samples=3):
     return rep, res
 
 
+def cpu_obj(units, seconds, kind, sample, cores=None, unit="query-points/s"):
+    """`cpu_baseline` object of a --config line: the reference's CPU path (kind "reference": oracle/_ref = its own nanoflann.hpp) or the
+    oracle's restatement (kind "port") timed on this box's host cores on a stated sample of the same workload."""
+    return {"value": units / seconds if seconds > 0 else None, "unit": unit, "cores": cores if cores is not None else (os.cpu_count() or 1),
+            "kind": kind, "cpu_model": cpu_model(), "seconds": round(seconds, 3), "sample": sample}
+
+
 def counters():
     """Issue-side counters and HBM traffic of the dominant kernel, from the round's rocprofv3 --pmc passes (tracked file)."""
     tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -282,21 +289,21 @@ def config_roofline(cfg, alg, step_s, k_ms, k_calls):
         ck = {}
     live_ms = k_ms / k_calls if k_calls else None
     prof_ms = ck["dominant_avg_us"] * ck.get("dominant_launches_per_call", 1.0) / 1e3 if ck.get("dominant_avg_us") else None
+    achieved = alg / step_s / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": ck.get("hbm_bytes_per_call"), "alg_bytes_per_call": alg,
+            "note": "whole operator call (all launches + host) against SURVEY 8d's algorithmic bytes; traffic = measured HBM bytes of the whole call "
+                    "(rocprofv3 --pmc, profiles/config_kernels.json: a tracked collection, see `source`)",
+            "source": ck.get("source"), "gpu_us_per_call_rocprof": ck.get("gpu_us_per_call")}
+    dom = {"kernel": ck.get("dominant"), "ms_live_hip_events": live_ms, "ms_rocprof": prof_ms, "traffic": ck.get("dominant_hbm_bytes_per_launch")}
     use_ms = live_ms or prof_ms
-    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "alg_bytes_per_call": alg,
-            "kernel": ck.get("dominant"), "kernel_ms_live_hip_events": live_ms, "kernel_ms_rocprof": prof_ms,
-            "traffic": ck.get("dominant_hbm_bytes_per_launch"), "traffic_whole_call": ck.get("hbm_bytes_per_call"),
-            "gpu_us_per_call_rocprof": ck.get("gpu_us_per_call"), "source": ck.get("source"),
-            "whole_op": {"achieved_GBps": alg / step_s / 1e9, "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "all launches + host against SURVEY 8d's algorithmic bytes"}}
     if use_ms:
-        roof["achieved"] = alg / (use_ms * 1e-3) / 1e9
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["timing"] = "HIP events around the main search launch of every 4th timed step" if live_ms else "rocprofv3 average of the same command (profiles/)"
-    else:
-        roof["achieved"] = alg / step_s / 1e9
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["timing"] = "whole op (no per-kernel figure available)"
+        dom["achieved"] = alg / (use_ms * 1e-3) / 1e9
+        dom["frac"] = dom["achieved"] / HBM_PEAK_GBS
+        dom["timing"] = ("HIP events around the main search launch, 4 extra steps outside the timed region (this build)" if live_ms
+                         else "rocprofv3 average of the same command in the tracked collection (may belong to an earlier build)")
+        dom["note"] = "the operator's algorithmic bytes over the dominant kernel's own duration"
+    roof["dominant_kernel"] = dom
     return roof
 
 
@@ -308,8 +315,11 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
     from conftest import cloud
     oracle.build()
     kind = "ref" if oracle.have_ref() else "port"
+    refkind = "reference" if kind == "ref" else "port"
+    cores_knn = (os.cpu_count() or 1) if kind == "ref" else 1        # (the reference's OpenMP search; the C restatement is serial)
     cfg = args.config
     parity = {}
+    cpu = {}                        # "obj": the line's cpu_baseline (filled by check(), which times the CPU path it compares with)
     if cfg in ("c2", "c3"):
         n, k = (1_000_000, 1) if cfg == "c2" else (4_000_000, 16)
         q, r = cloud(1000 + 2 * rank, n, np.float32), cloud(1001 + 2 * rank, n, np.float32)
@@ -320,7 +330,9 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         name = f"k_nearest_neighbors k={k}, {n}-vs-{n} fp32"
         def check():
             d, c = pcu.k_nearest_neighbors(tq, tr, k)
-            d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
+            t0 = time.perf_counter(); d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind); t_cpu = time.perf_counter() - t0
+            cpu["obj"] = cpu_obj(n, t_cpu, refkind, f"one full k_nearest_neighbors k={k} {n}-vs-{n} fp32 call on the GPU step's own arrays (input copies, 3x kd-tree build, "
+                                 f"OpenMP search on all cores, as the reference does; {t_cpu:.2f} s)", cores=cores_knn)
             return {"idx_equal": bool(np.array_equal(c.cpu().numpy(), c0)), "dist_bits_equal": bool(np.array_equal(d.cpu().numpy(), d0)), "stats": pcu.last_stats()}
     elif cfg == "c1":          # BASELINE config 1: the reference's CPU path on two 10k fp64 clouds is the expected result; the GPU call is timed
         n = 10_000
@@ -332,9 +344,10 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         def check():
             t0 = time.perf_counter(); ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=kind); t_cpu = time.perf_counter() - t0
             ch, cxy, cyx = pcu.chamfer_distance(tx, ty, return_index=True)
+            cpu["obj"] = cpu_obj(2 * n, t_cpu, refkind, f"one chamfer_distance(return_index=True) {n}-vs-{n} fp64 call, the config's own pair (below 100 000 rows the reference "
+                                 f"searches on one thread, src/point_cloud_distance.cpp:29-30; {t_cpu:.3f} s)", cores=1)
             return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
-                    "chamfer_rel": abs(float(ch) - float(ch0)) / float(ch0), "tol": 1e-6, "cpu_reference_seconds": t_cpu,
-                    "cpu_reference_value": 2 * n / t_cpu}
+                    "chamfer_rel": abs(float(ch) - float(ch0)) / float(ch0), "tol": 1e-6}
     elif cfg == "c4":
         # 32 pairs per GPU; pair p of the job's npairs x world pairs belongs to rank p mod world (batched.shard_pairs) and goes through
         # batched_hausdorff: the library's batch entry point per rank + the job's ONE all_gather of the scalars, inside the timed region
@@ -354,9 +367,13 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
                 return {"pairs_checked": 0, "note": "no step ran"}
             rows = last["rows"]               # rank 0 only: the rows the last timed step gathered (no further collective here)
             ok = True
+            t_cpu = 0.0
             for p in sorted(pairs):          # every pair of this rank against the reference
-                h0 = oracle.hausdorff_distance(pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy(), return_index=True, kind=kind)
+                a_, b_ = pairs[p][0].cpu().numpy(), pairs[p][1].cpu().numpy()
+                t0 = time.perf_counter(); h0 = oracle.hausdorff_distance(a_, b_, return_index=True, kind=kind); t_cpu += time.perf_counter() - t0
                 ok &= tuple(rows[p]) == tuple(float(v) for v in h0)
+            cpu["obj"] = cpu_obj(len(pairs) * 2 * n, t_cpu, refkind, f"hausdorff_distance of this rank's {len(pairs)} pairs ({n}-vs-{n} fp32), one after the other: the reference "
+                                 f"searches Hausdorff on ONE thread (num_threads = 0, src/point_cloud_distance.cpp:219); {t_cpu:.1f} s", cores=1)
             return {"pairs_checked": len(pairs), "tuples_equal": bool(ok)}
     elif cfg in ("gauss", "cluster", "outlier"):      # uneven clouds: Chamfer 1M-vs-1M fp32
         n = 1_000_000
@@ -375,7 +392,9 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         name = {"gauss": "chamfer_distance, 1M-vs-1M fp32 Gaussian sigma = 0.05", "cluster": "chamfer_distance, 1M-vs-1M fp32, 10 % of each cloud in a tight cluster (sigma 0.002)",
                 "outlier": "chamfer_distance, 1M-vs-1M fp32 uniform with one far outlier (bbox x 60)"}[cfg]
         def check():
-            ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=kind)
+            t0 = time.perf_counter(); ch0, cxy0, cyx0 = oracle.chamfer_distance(x, y, return_index=True, kind=kind); t_cpu = time.perf_counter() - t0
+            cpu["obj"] = cpu_obj(2 * n, t_cpu, refkind, f"one full chamfer_distance {n}-vs-{n} fp32 call on the GPU step's own pair (3x kd-tree build + OpenMP search per direction "
+                                 f"+ the numpy tail; {t_cpu:.2f} s)", cores=cores_knn)
             ch, cxy, cyx = pcu.chamfer_distance(tx, ty, return_index=True)
             return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
                     "chamfer_rel": abs(float(step()) - float(ch0)) / float(ch0), "tol": 1e-4, "stats": pcu.last_stats()}
@@ -396,8 +415,9 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
             t0 = time.perf_counter(); _, sv, vt = np.linalg.svd(a, full_matrices=False); t_svd = time.perf_counter() - t0
             good = (sv[:, 1] - sv[:, 2]) / sv[:, 0] > 1e-2
             dot = np.abs(np.einsum("ij,ij->i", nrm.cpu().numpy()[sel].astype(np.float64), vt[:, 2, :]))
-            return {"points_checked": int(good.sum()), "max_1_minus_abs_dot": float((1 - dot[good]).max()), "tol": 1e-6,
-                    "cpu_numpy_svd_points_per_s": 20000 / t_svd}
+            cpu["obj"] = cpu_obj(20000, t_svd, "port", "numpy batched SVD of 20 000 of the points' neighbourhoods (the plane fits only, without the KNN; the reference's "
+                                 "Eigen JacobiSVD is not in the checkout)", cores=1, unit="points/s")
+            return {"points_checked": int(good.sum()), "max_1_minus_abs_dot": float((1 - dot[good]).max()), "tol": 1e-6}
     elif cfg == "morton":           # element-wise integer kernel, the HBM-bound extreme
         n = 16_000_000
         pts = np.random.default_rng(rank).integers(-(1 << 20), 1 << 20, (n, 3)).astype(np.int32)
@@ -409,7 +429,8 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
             c = step().cpu().numpy().view(np.uint64)
             mk = "ref" if oracle.have_ref_morton() else "port"
             t0 = time.perf_counter(); c0 = oracle.morton_encode(pts[:2_000_000], mk); t_cpu = time.perf_counter() - t0
-            return {"codes_equal": bool(np.array_equal(c[:2_000_000], c0)), "checker": mk, "cpu_points_per_s_1core": 2_000_000 / t_cpu}
+            cpu["obj"] = cpu_obj(2_000_000, t_cpu, "reference" if mk == "ref" else "port", "the reference's own MortonCode64 over the first 2 000 000 points, one thread", cores=1, unit="points/s")
+            return {"codes_equal": bool(np.array_equal(c[:2_000_000], c0)), "checker": mk}
     elif cfg == "voxel":
         n = 1_000_000
         p = cloud(5 + rank, n, np.float32); tp = torch.from_numpy(p).to(dev)
@@ -422,7 +443,8 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
             v = step().cpu().numpy()
             t0 = time.perf_counter(); v0, _ = oracle.voxel_downsample(p[:200000], None, [vs] * 3, mb); t_cpu = time.perf_counter() - t0
             v1 = pcu.downsample_point_cloud_on_voxel_grid(vs, p[:200000], min_bound=mb, max_bound=xb)
-            return {"voxels": int(len(v)), "means_bit_equal_on_200k": bool(np.array_equal(v1, v0)), "cpu_points_per_s_1core_python": 200000 / t_cpu}
+            cpu["obj"] = cpu_obj(200000, t_cpu, "port", "Python restatement of src/sample_point_cloud.cpp:163-235 over the first 200 000 points, one thread", cores=1, unit="points/s")
+            return {"voxels": int(len(v)), "means_bit_equal_on_200k": bool(np.array_equal(v1, v0))}
     elif cfg == "sinkhorn":         # dense 4096 x 4096 cost matrix, 50 iterations
         m = n = 4096
         rng = np.random.default_rng(7 + rank)
@@ -438,8 +460,9 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
             P = step().cpu().numpy()
             t0 = time.perf_counter(); P0, _ = oracle.sinkhorn(wa.cpu().numpy()[:1024], wb.cpu().numpy()[:1024], M.cpu().numpy()[:1024, :1024] , 1e-2, 5, 0.0); t_cpu = time.perf_counter() - t0
             Pfull, it = oracle.sinkhorn(wa.cpu().numpy(), wb.cpu().numpy(), M.cpu().numpy(), 1e-2, iters, 0.0)
-            return {"plan_max_rel_err": float(np.abs(P - Pfull).max() / np.abs(Pfull).max()), "tol": 5e-4,
-                    "cpu_numpy_elements_x_iters_per_s": 5 * 1024 * 1024 / t_cpu}
+            cpu["obj"] = cpu_obj(5 * 1024 * 1024, t_cpu, "port", "the reference's numpy sinkhorn (_sinkhorn.py:36-130) on a 1024 x 1024 corner of the cost matrix, 5 iterations",
+                                 unit="elements*iterations/s")
+            return {"plan_max_rel_err": float(np.abs(P - Pfull).max() / np.abs(Pfull).max()), "tol": 5e-4}
     else:
         bunny = np.load(os.path.join(ROOT, "tests", "golden", "bunny_v.npy")).astype(np.float64)
         f = np.load(os.path.join(ROOT, "tests", "golden", "bunny_f.npy"))
@@ -451,35 +474,36 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
         name = "chamfer_distance(return_index=True), bunny (2,885 vertices) vs 1M mesh samples, fp64"
         def check():
             ch, cxy, cyx = step()
-            ch0, cxy0, cyx0 = oracle.chamfer_distance(bunny, S, return_index=True, kind=kind)
+            t0 = time.perf_counter(); ch0, cxy0, cyx0 = oracle.chamfer_distance(bunny, S, return_index=True, kind=kind); t_cpu = time.perf_counter() - t0
+            cpu["obj"] = cpu_obj(len(bunny) + len(S), t_cpu, refkind, f"one full chamfer_distance(return_index=True) call on the config's own clouds (the 2 885-row direction searches on one "
+                                 f"thread, the 1M-row direction on all cores; {t_cpu:.2f} s)", cores=cores_knn)
             return {"idx_equal": bool(np.array_equal(cxy.cpu().numpy(), cxy0) and np.array_equal(cyx.cpu().numpy(), cyx0)),
                     "chamfer_rel": abs(float(ch) - float(ch0)) / float(ch0), "tol": 1e-6}
     pcu.set_timing(0)
     step()
     for _ in range(args.warmup):
         step()
-    # per-kernel roofline input: HIP events around the call's main search launch(es), recorded by the library on its launch stream inside
-    # the timed region, on every 4th step (each event is a bubble between kernels); the batch entry point (c4) records none
-    KEV_EVERY = 4
-    k_ms, k_calls = 0.0, 0
     sync_all()
     t0 = time.perf_counter()
     for s_ in range(args.steps):
-        timed = (s_ % KEV_EVERY == 0) and cfg in ("c1", "c2", "c3", "c5", "gauss", "cluster", "outlier")
-        if timed:
-            pcu.set_timing(1)
         step()
-        if timed:
-            st = pcu.last_stats()
-            if st["n_kernel_search"] > 0:
-                k_ms += st["ms_kernel_search"]; k_calls += 1
-            pcu.set_timing(0)
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # dominant-kernel duration: HIP events around the call's main search launch(es), recorded by the library on its launch stream, in extra
+    # steps OUTSIDE the timed region (each event is a bubble between kernels); the batch entry point (c4) records none
+    k_ms, k_calls = 0.0, 0
+    if rank == 0 and cfg in ("c1", "c2", "c3", "c5", "gauss", "cluster", "outlier"):
+        pcu.set_timing(1)
+        for _ in range(4):
+            step()
+            st = pcu.last_stats()
+            if st["n_kernel_search"] > 0:
+                k_ms += st["ms_kernel_search"]; k_calls += 1
+        pcu.set_timing(0)
     if rank == 0:
         if not args.no_parity:
             parity = check()
@@ -492,6 +516,8 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
                           **({"collectives": "gloo on host tensors: REHEARSAL, ranks share GPUs (PCU_BENCH_SHARE_GPU)"} if args.share else {})},
                "roofline": config_roofline(cfg, alg, dt / steps, k_ms, k_calls),
                "parity": parity}
+        if "obj" in cpu and world == 1:
+            out["cpu_baseline"] = cpu["obj"]
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
