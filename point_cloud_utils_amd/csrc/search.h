@@ -924,10 +924,23 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
         //               without coarser grids or a host round trip per radius;
         //   wider box   if the box held fewer than k points, its radius grows four-fold (up to the whole grid).
         const bool esc = a.escalate && !g.closed;   // (a closed sub-box level does not hold the points beyond its box: nothing to finish there)
+        // distance from the query to the data's bounding box along y / z (0 inside; rounding-safe as in face_lower_bound): a lower bound for every
+        // dataset point. (Closed sub-box levels hold a subset of the data, for which the whole cloud's box is still a valid bound.)
+        T oy, oz;
+        { T m = g.gmin[1] - q.y, n_ = q.y - g.gmax[1]; m = m > n_ ? m : n_; oy = m > (T)0 ? m * shrink : (T)0; }
+        { T m = g.gmin[2] - q.z, n_ = q.z - g.gmax[2]; m = m > n_ ? m : n_; oz = m > (T)0 ? m * shrink : (T)0; }
         // < max_v: ball round with this bound. A straggler of the lane pass brings the k-th best that pass found: no box round needed.
         T ball = (esc && second && a.qbound2) ? a.qbound2[w - nq1] : Limits<T>::max_v;
         if (!(ball < Limits<T>::max_v)) ball = Limits<T>::max_v;          // (NaN never: d2 of kept candidates are ordered; defensive)
+        // (bound seeding, round 4) A box that holds fewer than k points says the query sits in a sparse part of the grid -- typically a query cloud
+        // far from the dataset, every query clamped to the same border cell. Growing the box four-fold until it holds k points made the first bound
+        // the k-th best of most of the grid, and the ball round behind it a scan of a thick cap of it (231k such queries against a 167k-point sphere,
+        // k = 16: 0.65 s, slower than the reference's kd-tree). Instead the wave first takes the k best of a stratified SUBSAMPLE of the dataset (up
+        // to 1024 records, evenly spaced in cell order): an upper bound of the k-th distance that is tight to within the sample's spacing, which the
+        // ball round then turns into the exact answer by scanning a thin shell.
+        bool seed_next = false, seeded = false;
         for (int round = 0;; ++round) {
+            const bool is_seed = seed_next;
             const bool is_ball = ball < Limits<T>::max_v;
             int x0, x1, y0, y1, z0, z1;
             if (!is_ball) {
@@ -951,8 +964,28 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
             // row and cell bounds, strict comparisons: what is skipped lies beyond the bound, ties included never) -- in ball rounds B only
             // shrinks, in box rounds a bound appears as soon as one lane holds K points. Batches go outward from the query's own row.
             // (231k queries at offset 1000 from a 167k-point sphere, k = 16: the first box with 16 points was the whole grid and every
-            // query scanned all of it, 1.6 s; scratch/case283.py.)
-            const int step = 64 / sp, nbat = (nrows + step - 1) / step;
+            // query scanned all of it, 1.6 s; scratch/case283.py.) A candidate beyond the batch's bound is not offered to the lists at all (round 4):
+            // the bound is at least the true k-th distance, so such a point is never among the k best, nor tied with the k-th -- and the K-wide
+            // insertion, which the whole wave executes whenever one lane accepts, is what a far query's thousands of shell candidates cost.
+            const int step = 64 / sp, nbat = is_seed ? 0 : (nrows + step - 1) / step;
+            if (is_seed) {
+                const unsigned nsamp = a.n_ref < 1024u ? a.n_ref : 1024u;
+                constexpr int kS = K <= 32 ? 4 : 1;
+                for (unsigned j0 = (unsigned)lane; j0 < nsamp; j0 += 64u * kS) {
+                    Pt4<T> cc[kS];
+#pragma unroll
+                    for (int u = 0; u < kS; ++u) {
+                        const unsigned j = min(j0 + 64u * (unsigned)u, nsamp - 1u);
+                        cc[u] = rec_at(a.ref, a.ref_xyz, a.ref_idx, a.n_ref < 1024u ? j : (unsigned)(((unsigned long long)j * (unsigned long long)a.n_ref) >> 10));
+                    }
+#pragma unroll
+                    for (int u = 0; u < kS; ++u) {
+                        const Pt4<T>& c = cc[u];
+                        const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                        take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && j0 + 64u * (unsigned)u >= nsamp), (int)c.idx);
+                    }
+                }
+            }
             const int cb = ((min(max(ccz, z0), z1) - z0) * ny + (min(max(ccy, y0), y1) - y0)) / step;
             T bw = Limits<T>::max_v;
             int b_lo = cb, b_hi = cb + 1;               // batches outward from the query's own, alternating sides
@@ -973,6 +1006,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                         if (cy > ccy) { const T m = face_above(g, 1, cy - 1) - q.y; my = m > (T)0 ? m * shrink : (T)0; }
                         if (cz < ccz) { const T m = q.z - face_below(g, 2, cz + 1); mz = m > (T)0 ? m * shrink : (T)0; }
                         if (cz > ccz) { const T m = face_above(g, 2, cz - 1) - q.z; mz = m > (T)0 ? m * shrink : (T)0; }
+                        my = my > oy ? my : oy; mz = mz > oz ? mz : oz;      // (a query outside the data's box: at least its distance to the box, also in its own -- clamped -- rows)
                         const T rlb = (my * my) + (mz * mz);
                         on = !(bound < rlb);
                         const T rx2 = bound * ((T)1 + (T)8 * Limits<T>::eps) - rlb;
@@ -999,7 +1033,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                     for (int u = 0; u < kU; ++u) {
                         const Pt4<T>& c = cc[u];
                         const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                        take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + (unsigned)u >= le), (int)c.idx);
+                        const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                        take(kill_if(d, (u > 0 && p + (unsigned)u >= le) || d > bound), (int)c.idx);      // (beyond the bound: never among the k best, see above)
                     }
                 }
                 // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
@@ -1023,7 +1058,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                         for (int u = 0; u < kH; ++u) {
                             const Pt4<T>& c = hc[u];
                             const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                            take(kill_if(((dx * dx) + (dy * dy)) + (dz * dz), u > 0 && p + 64u * (unsigned)u >= he), (int)c.idx);
+                            const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                            take(kill_if(d, (u > 0 && p + 64u * (unsigned)u >= he) || d > bound), (int)c.idx);
                         }
                     }
                 }
@@ -1056,11 +1092,17 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 if (j == kreq - 1) kth = md;
                 prev_d = md;
             }
+            if (is_seed) {                                          // the sample's k-th best bounds the answer; fewer than k records in it: wider boxes as before
+                seed_next = false;
+                if (kth < Limits<T>::max_v) ball = kth; else R = min(4 * R, 4096);
+                continue;
+            }
             certified = is_ball || kth < face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
             if (certified || !esc) break;
             if (kth < Limits<T>::max_v) ball = kth;                // k points seen: the ball round finishes the query
             else if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == Gx - 1 && y1 == Gy - 1 && z1 == Gz - 1) break;      // (cannot happen on an open grid: its whole box certifies)
-            else R = min(4 * R, 4096);                             // fewer than k points in the box: a wider one (whole grid: certified)
+            else if (!seeded) { seed_next = true; seeded = true; }  // fewer than k points in the box: a bound from the subsample first
+            else R = min(4 * R, 4096);                             // ... then a wider box (whole grid: certified)
         }
         if (certified && a.fuse != FUSE_NONE) {
             // fused epilogue (k = 1): the query's distance joins the direction's exact sum / this wave's arg-max; no row, no tie list
