@@ -29,7 +29,9 @@ def _ord_value(p):
 def _promote_pair(a, b):
     """The dtype numpy gives `norm(a - b)` (reference: _sinkhorn.py:30-32), by numpy's own promotion table: float32 stays float32 against
     float32 / float16 / bool / 8-bit integers, everything else is float64 (wider integers with float32, integers alone: the norm of an
-    integer array is float64). One difference: a float16 result is computed and returned in float32 (no half kernels)."""
+    integer array is float64). Two differences: a float16 result is computed and returned in float32 (no half kernels); and integers are
+    converted BEFORE the subtraction, so small integer types do not wrap around as numpy's `a - b` does (uint8 3 - 5 is -2 here, 254 there)
+    -- the distance of the values, not of their wrapped difference."""
     from . import _dtype_name, _is_torch
 
     def np_dtype(x):
@@ -93,7 +95,10 @@ def pairwise_distances(a, b, p=None):
     (a, b), (ctx, flags, stream, t, tdev), suf, npd = _prep([a, b])
     nb, m, d = (int(x) for x in a.shape); n = int(b.shape[1])
     out = _empty((nb, m, n), npd, t, tdev)
-    _lib.check(getattr(_lib.lib(), "pcu_hip_pairwise_" + suf)(ctx, _ptr(a), _ptr(b), nb, m, n, d, _ord_value(p), _ptr(out), flags, stream))
+    if d == 0:          # norm over an empty last axis: numpy gives zeros of shape (nb, m, n); the kernel has nothing to launch over
+        out = out.zero_() if t else np.zeros((nb, m, n), dtype=npd)
+    else:
+        _lib.check(getattr(_lib.lib(), "pcu_hip_pairwise_" + suf)(ctx, _ptr(a), _ptr(b), nb, m, n, d, _ord_value(p), _ptr(out), flags, stream))
     if squeezed:
         out = out.squeeze() if t else np.squeeze(out)
     return out

@@ -706,7 +706,9 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             lst = a.unresolved; cnt = a.n_unresolved;
             if (!last) {
                 // Possible ties of a sub-box level are put into total order ON that level: the lane pass certified them there, so every
-                // candidate of equal distance lies in the 27 cells it scanned. (Handed to the base grid -- round 2 -- each of them, a query
+                // candidate of equal distance lies in the 27 cells it scanned. (A closed level's wave pass does not escalate: what it cannot
+                // certify at radius 1 goes to u2 and takes the host-driven passes of search_finish on the base grid, one host round trip each --
+                // rare: a certified lane's ties sit inside its 27 cells.) (Handed to the base grid -- round 2 -- each of them, a query
                 // inside the cluster, scanned the base cell that holds the whole cluster: 1400 queries x 100k points = 0.45 ms per direction
                 // on the tight-cluster Chamfer.) What this launch cannot certify falls to the host-driven passes like any straggler.
                 SearchArgs<T> w = base_args(j, j.fine[lv]);
@@ -1130,12 +1132,14 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
             // ONE host round trip for the direction (the balance metric that brought us here, > 32 x the even value, already says that
             // levels are needed). If the statistics then say "base refit", what was enqueued is dropped.
             const double* hs_dev = nullptr; double hs[2] = {0, 0};
+            pcu_hip_stats before; if (st) before = *st;
             if (add_levels(j.ridx, &hs_dev)) return -1;
             if (search_enqueue(c, s, j, st)) return -1;
             HIP_TRY(hipMemcpyAsync(hs, hs_dev, sizeof hs, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             keep_base = hs[1] <= 0.5 * (double)j.ridx.n;
+            if (!keep_base && st) *st = before;          // (the attempt is dropped: its builds and passes are not the call's)
             if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d heavy points %.0f, level cells %.0f: %s\n", j.ridx.n, hs[1], hs[0], keep_base ? "grid kept" : "base refit");
         }
         if (!keep_base) {

@@ -122,3 +122,17 @@ def test_more_rows_than_a_grid_dimension_and_broadcast_inputs(pcu):
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     with pytest.raises(ValueError, match="broadcast"):
         pcu.pairwise_distances(rng.random((2, 4, 3)), rng.random((3, 4, 3)))
+
+
+def test_pairwise_empty_last_axis_and_small_integers(pcu):
+    """numpy's one-liner (_sinkhorn.py:30-32) on degenerate inputs: an empty last axis gives zeros of shape (m, n); small integers are
+    promoted before the subtraction here (no wrap-around: documented difference)."""
+    a, b = np.zeros((5, 0), np.float32), np.zeros((7, 0), np.float32)
+    M = pcu.pairwise_distances(a, b)
+    M0 = np.linalg.norm(a[:, None, :] - b[None, :, :], axis=-1)
+    assert M.shape == M0.shape == (5, 7) and M.dtype == M0.dtype and not M.any()
+    import torch
+    Mt = pcu.pairwise_distances(torch.zeros((2, 4, 0), device="cuda"), torch.zeros((2, 3, 0), device="cuda"))
+    assert tuple(Mt.shape) == (2, 4, 3) and not bool(Mt.any())
+    u, v = np.array([[3, 0, 0]], np.uint8), np.array([[5, 0, 0]], np.uint8)
+    assert pcu.pairwise_distances(u, v)[0, 0] == 2.0          # (numpy: 254.0, the norm of the wrapped difference)
