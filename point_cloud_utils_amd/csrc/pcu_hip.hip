@@ -23,7 +23,6 @@
 #include "grid2.h"
 #include "reduce.h"
 #include "search.h"
-#include "search_deal.h"
 namespace pcu {          // the k > 1 search kernels are compiled in search_kernels.hip (second translation unit, built in parallel)
 #define PCU_SEARCH_INST extern template
 #include "search_inst.h"
@@ -560,9 +559,9 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
         // (An LDS-staged, block-cooperative variant of this pass -- the north-star's tile design -- was measured again in round 4: 243-593 us
         // against 77 us, profiles/r04_flat_tile_ab.txt; removed.)
 #define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
-        static const bool deal = getenv("PCU_HIP_DEAL") != nullptr;          // (A/B switch: search_deal.h)
-        if (a.fuse == FUSE_SUM && deal) hipLaunchKernelGGL((k_search1_deal<T>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
-        else if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
+        // (a variant that deals a wave's candidate groups evenly to its lanes -- LDS list + atomic min -- measured 75.6 vs 76.5 us: the loop is
+        // not where the instructions are, profiles/r04_flat_deal_ab.txt; removed)
+        if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
         else if (a.fuse == FUSE_ARGMAX) PCU_FLAT(FUSE_ARGMAX);
         else PCU_FLAT(FUSE_NONE);
 #undef PCU_FLAT
