@@ -558,7 +558,7 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
         // (An LDS-staged, block-cooperative variant of this pass -- the north-star's tile design -- was measured again in round 4: 243-593 us
         // against 77 us, profiles/r04_flat_tile_ab.txt; removed.)
-#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
+#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, (sizeof(T) == 4 && FUSE == FUSE_SUM) ? 8 : 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
         // (a variant that deals a wave's candidate groups evenly to its lanes -- LDS list + atomic min -- measured 75.6 vs 76.5 us: the loop is
         // not where the instructions are, profiles/r04_flat_deal_ab.txt; removed)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
@@ -748,8 +748,9 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 // take the k = 1 lane kernel (few queries, tile / generic kernels selected by environment).
 template <typename T>
 static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_k1_kernel(); }
+// what == 1: only the lane pass; what == 2: only the wave pass; 3: both
 template <typename T>
-static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st) {
+static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st, int what = 3) {
     if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
         if (j0.fuse || j1.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue without the paired k = 1 pass");
         if (search_enqueue(c, s, j0, st, /*zero_counters=*/false)) return -1;
@@ -772,12 +773,17 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
         b[d].unresolved = sc.u2; b[d].n_unresolved = sc.counters + C_U2;
         b[d].escalate = wave_escalates();
     }
-    const bool time_it = st && c->time_kernels && c->n_kev + 2 <= 8;
-    if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
-    if (launch_search_fast<T>(1, a[0], j0.qidx.n, s, true, &a[1], j1.qidx.n)) return -1;
-    if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
-    if (launch_search_wave<T>(2, b[0], s, &b[1])) return -1;
-    if (st) st->n_passes += 4;
+    if (what & 1) {
+        const bool time_it = st && c->time_kernels && c->n_kev + 2 <= 8;
+        if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
+        if (launch_search_fast<T>(1, a[0], j0.qidx.n, s, true, &a[1], j1.qidx.n)) return -1;
+        if (time_it) { (void)hipEventRecord(c->kev[c->n_kev + 1], s); c->n_kev += 2; }
+        if (st) st->n_passes += 2;
+    }
+    if (what & 2) {
+        if (launch_search_wave<T>(2, b[0], s, &b[1])) return -1;
+        if (st) st->n_passes += 2;
+    }
     return 0;
 }
 
@@ -1483,6 +1489,7 @@ struct PairState {
     bool two = true;
     bool allow_rescale = true;                          // cleared on the last restart of a call (occupancy rescale)
     int fuse = FUSE_NONE; FuseTail<T> tail;             // fused attempt (tail: arguments of the launch that ends the call)
+    bool wave_pending = false;                          // the fused attempt's wave-per-query pass has not been launched (pair_search_enqueue)
     int* tie_hit = nullptr;
 };
 template <typename T>
@@ -1497,14 +1504,42 @@ static size_t pair_bytes(int64_t nx, int64_t ny, double occ_x, double occ_y, boo
                       align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256);
     return b;
 }
+// A fused two-sided attempt is lane pass + fold: the k = 1 lane kernel finishes its own stragglers (search.h: radius 2 inside the lane), so the
+// wave-per-query pass -- a launch on the critical path of every call for a few hundred queries -- runs only when a direction's lists are not
+// empty afterwards (fused_needs_wave; then: wave pass + a second fold). PCU_HIP_FUSED_WAVE=1 launches it up front as before.
+static int wait_result_block(pcu_hip_ctx* c, hipStream_t s);
+static bool fused_wave_upfront() { static const bool v = getenv("PCU_HIP_FUSED_WAVE") != nullptr; return v; }
 template <typename T>
 static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st) {
-    if (P.two) { if (search_enqueue_pair(c, s, P.xy, P.yx, st)) return -1; }
+    const bool lazy_wave = P.fuse && P.two && !fused_wave_upfront() && lane_k1_job(P.xy) && lane_k1_job(P.yx);
+    if (P.two) { if (search_enqueue_pair(c, s, P.xy, P.yx, st, lazy_wave ? 1 : 3)) return -1; }
     else if (search_enqueue(c, s, P.xy, st, /*zero_counters=*/false)) return -1;
+    P.wave_pending = lazy_wave;
     if (P.fuse) {               // the launch that ends a fused call (reduce.h)
+        P.tail.nwaves = lazy_wave ? 0 : kWaveBlocks * (kBlock / 64);       // (no wave pass yet: its per-wave slots hold nothing)
         hipLaunchKernelGGL(k_fuse_tail<T>, dim3(1), dim3(kTailThreads), 0, s, P.tail);
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+// The first fold of a lazy fused attempt has arrived: do some queries still need the wave-per-query pass (stragglers beyond radius 2, lanes that
+// deferred next to a heavy cell)? Then run it now, fold again, and wait for that result block.
+template <typename T>
+static int fused_wave_if_needed(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock& host) {
+    if (!P.wave_pending) return 0;
+    P.wave_pending = false;
+    bool need = false, broken = false;
+    for (int d = 0; d < 2; ++d) {
+        need = need || host.counters[d][C_U1] > 0 || host.counters[d][C_T1] > 0;
+        broken = broken || host.counters[d][C_SKEW] || host.counters[d][C_LARGE];
+    }
+    if (!need || broken) return 0;            // (a pass that gave up listed nothing: the row-based path takes the call over)
+    if (search_enqueue_pair(c, s, P.xy, P.yx, st, 2)) return -1;
+    P.tail.nwaves = kWaveBlocks * (kBlock / 64); P.tail.seq = ++c->seq;
+    hipLaunchKernelGGL(k_fuse_tail<T>, dim3(1), dim3(kTailThreads), 0, s, P.tail);
+    HIP_TRY(hipGetLastError());
+    if (wait_result_block(c, s)) return -1;
+    memcpy(&host, c->h_pinned, sizeof host);
     return 0;
 }
 template <typename T>
@@ -1766,6 +1801,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
             tm.mark(3);
             if ((rc = wait_result_block(c, s))) break;
             memcpy(&host, c->h_pinned, sizeof host);
+            if ((rc = fused_wave_if_needed(c, s, P, st, host))) break;
             if (pair_refused_nonfinite(P, host)) {          // non-finite coordinates: row-based, if the reference has a stable answer
                 int nf[2];
                 if ((rc = pair_nonfinite_flags(s, P, nf))) break;
@@ -1904,6 +1940,7 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
             if ((rc = wait_result_block(c, s))) break;
             g_hprof.mark(3);
             memcpy(&host, c->h_pinned, sizeof host);
+            if ((rc = fused_wave_if_needed(c, s, P, st, host))) break;
             if (pair_refused_nonfinite(P, host)) {          // non-finite coordinates: see below (nan_rule) and hausdorff_end
                 int nf[2];
                 if ((rc = pair_nonfinite_flags(s, P, nf))) break;

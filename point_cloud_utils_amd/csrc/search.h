@@ -762,6 +762,73 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
             if (!live) break;
         }
     }
+    // ---- radius 2, inside the launch (fused calls; round 4). A query whose best is not certified by the 27 cells -- its nearest neighbour may lie
+    // beyond them: 2 in 10,000 queries of a uniform cloud -- used to go to the wave-per-query pass: a launch of its own on the critical path of
+    // every fused call (10.5 of 164 us at 1M-vs-1M) for a few hundred queries. Now the query's own wave serves it, the way that pass would: the
+    // 5 x 5 rows x 5 cells around its cell are dealt to the lanes (a row each; one lane alone would walk ~125 dependent round trips and hold its
+    // wave for longer than the rest of the launch takes -- measured: +19 us), every lane scans its row from scratch against the broadcast query,
+    // a wave reduction picks the winner, and the query is certified against that box. The wave pass is launched only when a call's lists are not
+    // empty afterwards (pcu_hip.hip: fused_wave_if_needed). Waves with exited lanes (the last of a cloud) leave their stragglers to it.
+    int cx0 = x0, cx1 = x1;                              // the box of cells the result is certified against
+    int cy0 = max(ccy - 1, 0), cy1 = min(ccy + 1, Gy - 1), cz0 = max(ccz - 1, 0), cz1 = min(ccz + 1, Gz - 1);
+    T lb = (T)0;                                         // (fused calls) the certification bound of that box
+#ifndef PCU_NO_RESCUE
+#define PCU_NO_RESCUE 0
+#endif
+    if (FUSE != FUSE_NONE) {
+        lb = face_lower_bound_inner(g, q.x, q.y, q.z, cx0, cx1, cy0, cy1, cz0, cz1);
+        unsigned long long todo = __ballot(valid && !defer && !(best < lb));
+        if (!PCU_NO_RESCUE && todo && __ballot(true) == ~0ull) {
+            const int lane_ = tid & 63;
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                Pt4<T> sq;                                                   // the straggler's query, in scalar registers
+                sq.x = __shfl(q.x, l, 64); sq.y = __shfl(q.y, l, 64); sq.z = __shfl(q.z, l, 64); sq.idx = 0;
+                const int scx = grid_cell(g, 0, sq.x), scy = grid_cell(g, 1, sq.y), scz = grid_cell(g, 2, sq.z);
+                const int bx0 = max(scx - 2, 0), bx1 = min(scx + 2, Gx - 1), by0 = max(scy - 2, 0), by1 = min(scy + 2, Gy - 1);
+                const int bz0 = max(scz - 2, 0), bz1 = min(scz + 2, Gz - 1);
+                const int ny_ = by1 - by0 + 1, nrows = ny_ * (bz1 - bz0 + 1);
+                // two lanes per row of the box (<= 25 rows), each scans its half from scratch with its own running minimum
+                T wbest = Limits<T>::max_v; unsigned wboff = 0xffffffffu, wtoff = 0xffffffffu; bool wtie = false, wtie2 = false;
+                if ((lane_ >> 1) < nrows) {
+                    const int r_ = lane_ >> 1;
+                    const unsigned lo = (unsigned)row_run_lo(Gx, grid_row(Gy, by0 + r_ % ny_, bz0 + r_ / ny_), bx0, bx1);
+                    const unsigned rs_ = a.cell_start[lo], re_ = a.cell_start[lo + (unsigned)(bx1 - bx0 + 1)];
+                    const unsigned mid = rs_ + (((re_ - rs_ + 1u) >> 1) + 3u) / 4u * 4u;            // (whole groups in the first half: no record is seen twice)
+                    const unsigned s_ = ((lane_ & 1) ? min(mid, re_) : rs_) * kRec, e_ = ((lane_ & 1) ? re_ : min(mid, re_)) * kRec;
+                    for (unsigned off_ = s_; off_ < e_; off_ += (unsigned)kG * kRec) {
+                        T d_[4]; GE::dists(GE::load(base, off_), sq, d_);
+                        if (!(lane_ & 1)) {                                   // (the first half's last group stops at the half's end)
+#pragma unroll
+                            for (int u = 1; u < 4; ++u) d_[u] = off_ + (unsigned)u * kRec >= e_ ? (T)INFINITY : d_[u];      // (+inf, not kill_if's bit pattern: a signalling NaN would poison the v_min chain)
+                        }
+                        const T m_ = min4(d_[0], d_[1], d_[2], d_[3]);
+                        const bool eq_ = m_ == wbest, lt_ = m_ < wbest;
+                        if (FUSE != FUSE_SUM) { wtie2 = !lt_ && (wtie2 || (wtie && eq_)); wtie = !lt_ && (wtie || eq_); wtoff = eq_ ? off_ : wtoff; wboff = lt_ ? off_ : wboff; }
+                        wbest = lt_ ? m_ : wbest;
+                    }
+                }
+                T mn = wbest;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const T ot = __shfl_xor(mn, o, 64); mn = ot < mn ? ot : mn; }
+                const T lb2 = face_lower_bound_inner(g, sq.x, sq.y, sq.z, bx0, bx1, by0, by1, bz0, bz1);
+                if (FUSE == FUSE_SUM) {                                       // (the sum needs the value only)
+                    if (lane_ == l) { best = mn; lb = lb2; cx0 = bx0; cx1 = bx1; cy0 = by0; cy1 = by1; cz0 = bz0; cz1 = bz1; }
+                    continue;
+                }
+                const unsigned long long eqm = __ballot(wbest == mn && wboff != 0xffffffffu);
+                const int wl = eqm ? __ffsll((long long)eqm) - 1 : 0;        // a lane that holds the minimum
+                const bool many = __popcll(eqm) > 1;                          // ... met by two lanes: a possible tie
+                const unsigned rb = (unsigned)__shfl((int)wboff, wl, 64), rt = many ? (unsigned)__shfl((int)wboff, 63 - __clzll((long long)eqm), 64) : (unsigned)__shfl((int)wtoff, wl, 64);
+                const bool rtie = many || __shfl((int)wtie, wl, 64), rtie2 = (many && __popcll(eqm) > 2) || __shfl((int)wtie2, wl, 64) || (many && __shfl((int)wtie, wl, 64));
+                if (lane_ == l) {
+                    best = mn; lb = lb2; boff = eqm ? rb : 0xffffffffu; toff = rt; tie = rtie; tie2 = rtie2;
+                    cx0 = bx0; cx1 = bx1; cy0 = by0; cy1 = by1; cz0 = bz0; cz1 = bz1;
+                }
+            }
+        }
+    }
 #undef PCU_K1_EVAL
     // ---- which record of the winning group it was; ties (see k_search1)
     T bd[1] = {best};
@@ -787,15 +854,12 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
             if (h2 == 1 && ro2 == ro) tie = false;        // the same record met twice (groups run past their run's end)
         }
     }
-    const int y0 = max(ccy - 1, 0), y1 = min(ccy + 1, Gy - 1);
-    const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, Gz - 1);
-    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, x0, x1, y0, y1, z0, z1, bd, bi, tie, valid, defer); return; }
+    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, cx0, cx1, cy0, cy1, cz0, cz1, bd, bi, tie, valid, defer); return; }
     // fused epilogue: the lane's distance goes into the block's partial (kernel wrapper) instead of a result row
     if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
         wave_append(valid, qpos, a.ties, a.n_ties);
         return;
     }
-    const T lb = face_lower_bound_inner(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
     const bool certified = valid && best < lb;
     const int us = wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
     if (us >= 0 && a.ubound) a.ubound[us] = best;

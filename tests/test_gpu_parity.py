@@ -204,6 +204,16 @@ def test_full_size_chamfer_and_hausdorff_consistency(pcu):
     assert np.array_equal(cxy, c1) and np.array_equal(cyx, c2)
     ref = np.float32(np.linalg.norm(x[cyx] - y, axis=-1).mean()) + np.float32(np.linalg.norm(y[cxy] - x, axis=-1).mean())
     assert abs(float(ch) - float(ref)) <= 1e-4 * float(ref)
+    # the fused call's fp64 means (C ABI, before the wrapper rounds them to the input dtype) against the fp64 sums of the rows: every query's
+    # distance is in the sum exactly once -- one query served a wrong neighbour moves the mean by ~1e-9 relative, far above fp64 rounding
+    import ctypes
+    from point_cloud_utils_amd import _Dev, _fn, Stats
+    dv = _Dev(x, y); means = (ctypes.c_double * 2)(); st = Stats()
+    rc = _fn("chamfer", dv.suffix)(dv.ctx, dv.pa, n, dv.pb, n, 2.0, 10, ctypes.addressof(means), None, None, dv.flags, dv.stream, ctypes.addressof(st))
+    assert rc == 0
+    for got, rows in ((means[0], dxy), (means[1], dyx)):
+        want = float(rows.astype(np.float64).sum()) / n
+        assert abs(got - want) <= 1e-11 * want, (got, want)
     h, i, j = pcu.hausdorff_distance(x, y, return_index=True)
     assert h == float(max(dxy.max(), dyx.max()))
     if dxy.max() > dyx.max():
