@@ -668,8 +668,11 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
 // Enqueue (no host sync): lane-per-query pass at R=1 over all queries, then ONE wave-per-query launch fed by two
 // device-side lists: possible ties (radius 1, total order) and stragglers (radius 2). What is still uncertified after
 // that (list u2; next to nothing on balanced clouds) is finished by search_finish's host-driven loop.
+// what: 1 = the lane passes only, 2 = only the wave-per-query launch that follows them, 3 = both (wave-only jobs: always everything)
 template <typename T>
-static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true) {
+static bool lazy_wave_job(const SearchJob<T>& j);
+template <typename T>
+static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, pcu_hip_stats* st, bool zero_counters = true, int what = 3) {
     const SearchScratch<T>& sc = j.sc;
     const int KF = pow2_at_least(j.k), KL = std::max(2, pow2_at_least(j.k + 1));
     if (zero_counters) HIP_TRY(hipMemsetAsync(sc.counters, 0, C_N * sizeof(int), s));
@@ -682,7 +685,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         // Lane-per-query passes, finest dataset grid first: a query is served by the finest grid that certifies it
         // (dense regions), the rest falls through to the coarser grids (sparse regions) and finally to `ridx`.
         const int* lst = nullptr; const int* cnt = nullptr;
-        for (int lv = 0; lv <= j.n_fine; ++lv) {
+        for (int lv = 0; lv <= ((what & 1) ? j.n_fine : -1); ++lv) {
             const bool last = lv == j.n_fine;
             SearchArgs<T> a = base_args(j, last ? j.ridx : j.fine[lv]);
             a.qlist = lst; a.qcount_dev = cnt; a.nq = j.qidx.n; a.R = 1;
@@ -725,8 +728,8 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         b.qbound2 = sc.ub1;
         b.unresolved = sc.u2; b.n_unresolved = sc.counters + C_U2;
         b.escalate = wave_escalates();                                           // ... and whatever it takes after that, inside the launch
-        if (launch_search_wave<T>(KL, b, s)) return -1;
-        if (st) st->n_passes += 2 + j.n_fine;
+        if ((what & 2) && launch_search_wave<T>(KL, b, s)) return -1;
+        if (st) st->n_passes += ((what & 1) ? 1 + j.n_fine : 0) + ((what & 2) ? 1 : 0);
     } else {
         if (j.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
@@ -749,6 +752,10 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
 template <typename T>
 static bool lane_k1_job(const SearchJob<T>& j) { return j.k == 1 && j.qidx.n >= kWaveOnlyBelow && j.n_fine == 0 && use_k1_kernel(); }
 // what == 1: only the lane pass; what == 2: only the wave pass; 3: both
+// A k = 1 lane job on an open index finishes its stragglers inside the lane launch (search.h: radius 2 by the query's own wave): its wave pass
+// can wait until the counters say that something is left.
+template <typename T>
+static bool lazy_wave_job(const SearchJob<T>& j) { static const bool off = getenv("PCU_HIP_FUSED_WAVE") != nullptr; return !off && lane_k1_job(j); }
 template <typename T>
 static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st, int what = 3) {
     if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
@@ -1425,13 +1432,23 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         if (st) st->n_grid_builds += pidx ? 1 : 2;
         tm.mark(1);
         const bool spec = kd_speculate_fork(c, s, job);
-        if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false))) break;
+        const bool lazy_wave = lazy_wave_job(job);          // (k = 1: the wave pass only if the lane launch leaves something, see below)
+        if ((rc = search_enqueue(c, s, job, st, /*zero_counters=*/false, lazy_wave ? 1 : 3))) break;
         if (spec && (rc = kd_speculate(c, ar, s, job))) break;
         if (row_out) { hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError()); }
         else if ((rc = unpermute_enqueue(s, job, dd, di, rb, c->h_pinned, ++c->seq))) break;   // optimistic: redone below if stragglers / ties remain
         tm.mark(2);
         HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
         if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
+        if (lazy_wave) {
+            const int* hc0 = ((ResultBlock*)c->h_pinned)->counters[0];
+            if ((hc0[C_U1] > 0 || hc0[C_T1] > 0) && !hc0[C_SKEW] && !hc0[C_LARGE]) {       // stragglers beyond radius 2, possible ties, deferred lanes: the wave pass now
+                if ((rc = search_enqueue(c, s, job, st, false, 2))) break;
+                hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));
+                if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
+            }
+        }
         if ((rc = search_finish(c, ar, s, job, st, ((ResultBlock*)c->h_pinned)->counters[0])) < 0) { if (rc == PCU_NONFINITE) rc = nonfinite_error(false); break; }
         if (rc == 3) { rc = PCU_RETRY; break; }
         if (row_out) { if (rc > 0) tm.mark(2); }

@@ -762,23 +762,25 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
             if (!live) break;
         }
     }
-    // ---- radius 2, inside the launch (fused calls; round 4). A query whose best is not certified by the 27 cells -- its nearest neighbour may lie
+    // ---- radius 2, inside the launch (round 4). A query whose best is not certified by the 27 cells -- its nearest neighbour may lie
     // beyond them: 2 in 10,000 queries of a uniform cloud -- used to go to the wave-per-query pass: a launch of its own on the critical path of
-    // every fused call (10.5 of 164 us at 1M-vs-1M) for a few hundred queries. Now the query's own wave serves it, the way that pass would: the
+    // every k = 1 call (10.5 of 164 us at 1M-vs-1M Chamfer) for a few hundred queries. Now the query's own wave serves it, the way that pass would: the
     // 5 x 5 rows x 5 cells around its cell are dealt to the lanes (a row each; one lane alone would walk ~125 dependent round trips and hold its
     // wave for longer than the rest of the launch takes -- measured: +19 us), every lane scans its row from scratch against the broadcast query,
     // a wave reduction picks the winner, and the query is certified against that box. The wave pass is launched only when a call's lists are not
-    // empty afterwards (pcu_hip.hip: fused_wave_if_needed). Waves with exited lanes (the last of a cloud) leave their stragglers to it.
+    // empty afterwards (pcu_hip.hip: fused_wave_if_needed, knn_attempt). Waves with exited lanes (the last of a cloud) leave their stragglers to it.
     int cx0 = x0, cx1 = x1;                              // the box of cells the result is certified against
     int cy0 = max(ccy - 1, 0), cy1 = min(ccy + 1, Gy - 1), cz0 = max(ccz - 1, 0), cz1 = min(ccz + 1, Gz - 1);
-    T lb = (T)0;                                         // (fused calls) the certification bound of that box
+    T lb = (T)0;                                         // the certification bound of that box
 #ifndef PCU_NO_RESCUE
 #define PCU_NO_RESCUE 0
 #endif
-    if (FUSE != FUSE_NONE) {
+    {
         lb = face_lower_bound_inner(g, q.x, q.y, q.z, cx0, cx1, cy0, cy1, cz0, cz1);
         unsigned long long todo = __ballot(valid && !defer && !(best < lb));
-        if (!PCU_NO_RESCUE && todo && __ballot(true) == ~0ull) {
+        // (more than a few of them in one wave is not bad luck but the shape of the input -- a query cloud away from the dataset, every lane
+        // uncertified: those go to the wave pass, whose rounds are built for it, without 64 futile box scans per wave first)
+        if (!PCU_NO_RESCUE && todo && __popcll(todo) <= 4 && __ballot(true) == ~0ull) {
             const int lane_ = tid & 63;
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;

@@ -135,4 +135,4 @@ def test_pairwise_empty_last_axis_and_small_integers(pcu):
     Mt = pcu.pairwise_distances(torch.zeros((2, 4, 0), device="cuda"), torch.zeros((2, 3, 0), device="cuda"))
     assert tuple(Mt.shape) == (2, 4, 3) and not bool(Mt.any())
     u, v = np.array([[3, 0, 0]], np.uint8), np.array([[5, 0, 0]], np.uint8)
-    assert pcu.pairwise_distances(u, v)[0, 0] == 2.0          # (numpy: 254.0, the norm of the wrapped difference)
+    assert float(pcu.pairwise_distances(u, v)) == 2.0          # (numpy: 254.0, the norm of the wrapped difference; a 1 x 1 result is squeezed to 0-d)
