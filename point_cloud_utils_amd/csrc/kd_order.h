@@ -369,6 +369,296 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
     if (threadIdx.x == 0) { b.next_cbase[n_next] = s_items; *b.n_items = s_items; *b.n_next = n_next; }
 }
 
+// ---- one workgroup per node, elements in place ----------------------------------------------------------------------------------------
+// Once the level passes have brought the nodes down to a few ten thousand elements, a level is ~9 launches of 3-5 us that each
+// touch little data -- with regions of interest only a few dozen nodes are still alive and the chain of launches IS the cost (round
+// 3, config 3: 0.55 ms for six such levels). From there on one workgroup takes a node of the level list and finishes everything
+// below it that the level passes would: the same choose / count / ranked misplaced lists / pairwise swap (twice when elements equal
+// the cut value) / split, with __syncthreads() for kernel boundaries and the elements in global memory (a node is L2-resident);
+// children that fit the LDS sub-tree kernel go to its list, children outside every region of interest become stubs (their tight
+// box is computed here, with the sibling's, in one pass over the parent), the others are pushed on the workgroup's own stack
+// (larger child first, so the stack stays below log2 of the node). Nodes are independent, so nothing is synchronised across
+// workgroups; node ids come from the global allocator (their order is not part of the tree).
+constexpr int kFinThreads = 1024;
+constexpr int kFinBatch = 8;
+
+template <typename T>
+__device__ __forceinline__ void kd_fin_minmax(const Pt4<T>* __restrict__ E, int s, int e, T (&lo)[3], T (&hi)[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { lo[j] = Limits<T>::max_v; hi[j] = -Limits<T>::max_v; }
+#pragma unroll 1
+    for (int base = s + (int)threadIdx.x; base < e; base += kFinThreads * 4) {
+        Pt4<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int p = base + u * kFinThreads; v[u] = E[p < e ? p : base]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo[0] = v[u].x < lo[0] ? v[u].x : lo[0]; hi[0] = v[u].x > hi[0] ? v[u].x : hi[0];
+            lo[1] = v[u].y < lo[1] ? v[u].y : lo[1]; hi[1] = v[u].y > hi[1] ? v[u].y : hi[1];
+            lo[2] = v[u].z < lo[2] ? v[u].z : lo[2]; hi[2] = v[u].z > hi[2] ? v[u].z : hi[2];
+        }
+    }
+}
+
+// tight boxes of [s, m) and [m, e) in one pass
+template <typename T>
+__device__ __forceinline__ void kd_fin_minmax2(const Pt4<T>* __restrict__ E, int s, int m, int e, T (&lo)[3], T (&hi)[3], T (&lo2)[3], T (&hi2)[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { lo[j] = lo2[j] = Limits<T>::max_v; hi[j] = hi2[j] = -Limits<T>::max_v; }
+#pragma unroll 1
+    for (int base = s + (int)threadIdx.x; base < e; base += kFinThreads * 4) {
+        Pt4<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int p = base + u * kFinThreads; v[u] = E[p < e ? p : base]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = base + u * kFinThreads;
+            const bool a = (p < e ? p : base) < m;
+            const T big = Limits<T>::max_v;
+            // an element takes part in one box only: for the other it is replaced by the neutral value
+            const T xa = a ? v[u].x : big, ya = a ? v[u].y : big, za = a ? v[u].z : big;
+            const T xb = a ? big : v[u].x, yb = a ? big : v[u].y, zb = a ? big : v[u].z;
+            lo[0] = xa < lo[0] ? xa : lo[0]; lo[1] = ya < lo[1] ? ya : lo[1]; lo[2] = za < lo[2] ? za : lo[2];
+            lo2[0] = xb < lo2[0] ? xb : lo2[0]; lo2[1] = yb < lo2[1] ? yb : lo2[1]; lo2[2] = zb < lo2[2] ? zb : lo2[2];
+            const T xc = a ? v[u].x : -big, yc = a ? v[u].y : -big, zc = a ? v[u].z : -big;
+            const T xd = a ? -big : v[u].x, yd = a ? -big : v[u].y, zd = a ? -big : v[u].z;
+            hi[0] = xc > hi[0] ? xc : hi[0]; hi[1] = yc > hi[1] ? yc : hi[1]; hi[2] = zc > hi[2] ? zc : hi[2];
+            hi2[0] = xd > hi2[0] ? xd : hi2[0]; hi2[1] = yd > hi2[1] ? yd : hi2[1]; hi2[2] = zd > hi2[2] ? zd : hi2[2];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kFinThreads) void k_kd_finish(KdBuild<T> b) {
+    typedef typename EncT<T>::type Enc;
+    __shared__ int s_stack[64];
+    __shared__ int s_i[8];                               // [0] lt [1] le [2] first child id [3] stack size [4] root is a stub
+    __shared__ unsigned s_cnt[kFinThreads / 64][2];
+    __shared__ T s_red[kFinThreads / 64][12];
+    __shared__ T s_mm[12];                               // lo xyz, hi xyz of the first range; the same of the second
+    __shared__ T s_roi[4 * kKdMaxRoi];
+    __shared__ int s_in[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_level = *b.n_cur;
+    const int n_roi = *b.n_roi;
+    for (int i = tid; i < 4 * n_roi; i += kFinThreads) s_roi[i] = b.roi[i];
+    // box [lo, hi] against the regions: waves 0 and 1 test the two boxes handed in (kd_in_roi's arithmetic, one region per lane)
+    auto in_roi2 = [&](const T (&box0)[6], const T (&box1)[6]) {
+        if (wave < 2) {
+            T bx[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) bx[j] = wave ? box1[j] : box0[j];
+            bool hit = n_roi == 0;
+            if (lane < n_roi) {
+                const T* q = s_roi + 4 * lane;
+                T d2 = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const T a = bx[j] - q[j], c = q[j] - bx[3 + j]; const T m = a > c ? a : c; if (m > 0) d2 += m * m; }
+                hit = !(d2 > q[3]);
+            }
+            const bool any = __ballot(hit) != 0ull;
+            if (lane == 0) s_in[wave] = any ? 1 : 0;
+        }
+    };
+    auto fold_mm = [&](const T (&lo)[3], const T (&hi)[3], int slot) {     // per-wave part of a block min/max; slot 0 / 1 = first / second range
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const T a = wave_min(lo[j]), c = wave_max(hi[j]);
+            if (lane == 0) { s_red[wave][6 * slot + j] = a; s_red[wave][6 * slot + 3 + j] = c; }
+        }
+    };
+    auto finish_mm = [&](int n_slots) {                   // (after a barrier) threads 0 .. 6 n_slots - 1 fold the waves
+        if (tid < 6 * n_slots) {
+            const bool is_min = (tid % 6) < 3;
+            T r = s_red[0][tid];
+            for (int w = 1; w < kFinThreads / 64; ++w) { const T x = s_red[w][tid]; r = is_min ? (x < r ? x : r) : (x > r ? x : r); }
+            s_mm[tid] = r;
+        }
+    };
+#pragma unroll 1
+    for (int li = blockIdx.x; li < n_level; li += gridDim.x) {
+        if (tid == 0) s_i[3] = 0;
+        __syncthreads();
+        int id = b.level_nodes[li];
+        bool from_level = true;                           // the level list's nodes do not have their tight box yet
+#pragma unroll 1
+        for (;;) {
+            KdNode<T>& nd = b.nodes[id];
+            const int left = nd.left, right = nd.right, count = right - left;
+            T bb[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { bb[j] = nd.bb_lo[j]; bb[3 + j] = nd.bb_hi[j]; }
+            if (from_level) {
+                T lo[3], hi[3];
+                kd_fin_minmax(b.E, left, right, lo, hi);
+                fold_mm(lo, hi, 0);
+                if (tid == 0) s_i[4] = nd.active;
+                __syncthreads();
+                finish_mm(1);
+                in_roi2(bb, bb);
+                __syncthreads();
+                if (tid < 3 && s_mm[tid] <= s_mm[3 + tid]) { nd.mm_lo[tid] = enc(s_mm[tid]); nd.mm_hi[tid] = enc(s_mm[3 + tid]); }
+                // a node handed over by complete (speculative) top levels is tested against the regions here
+                const bool stub = s_i[4] || (count > b.leaf_max && !s_in[0]);
+                if (stub) { if (tid == 0) nd.active = 1; break; }
+            }
+            T mn[3], mx[3];
+            if (from_level) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { mn[j] = s_mm[j]; mx[j] = s_mm[3 + j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { mn[j] = dec(nd.mm_lo[j]); mx[j] = dec(nd.mm_hi[j]); }
+            }
+            int f; T cut;
+            kd_choose(bb, bb + 3, mn, mx, f, cut);
+            f = __builtin_amdgcn_readfirstlane(f);
+            const T* const coord = reinterpret_cast<const T*>(b.E) + f;      // coordinate f of element p: coord[4 p]
+            const int depth = nd.depth;
+            __syncthreads();                              // (s_mm, s_in are free again)
+            // lim1, lim2
+            {
+                unsigned lt = 0, le = 0;
+#pragma unroll 1
+                for (int base = left + tid; base < right; base += kFinThreads * kFinBatch) {
+                    T v[kFinBatch];
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) { const int p = base + u * kFinThreads; v[u] = p < right ? coord[4 * (size_t)p] : Limits<T>::max_v; }
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) { const bool on = base + u * kFinThreads < right; lt += on && v[u] < cut; le += on && v[u] <= cut; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); le += __shfl_xor(le, o, 64); }
+                if (lane == 0) { s_cnt[wave][0] = lt; s_cnt[wave][1] = le; }
+                __syncthreads();
+                if (tid < 2) { unsigned r = 0; for (int w = 0; w < kFinThreads / 64; ++w) r += s_cnt[w][tid]; s_i[tid] = (int)r; }
+                __syncthreads();
+            }
+            const int lim1 = s_i[0], lim2 = s_i[1];
+            // planeSplit: ranked misplaced lists + pairwise swap. Wave w owns the w-th sixteenth of the node's positions and walks it 64
+            // consecutive positions at a time (coalesced), so ranks follow position order: rank = misplaced elements of earlier waves
+            // + of this wave's earlier steps + of the lower lanes (ballot).
+            const int wpt = (count + kFinThreads / 64 - 1) / (kFinThreads / 64);
+            const int w0 = min(left + wave * wpt, right), w1 = min(w0 + wpt, right);
+            const unsigned long long lower = (1ull << lane) - 1ull;
+#pragma unroll 1
+            for (int ph = 0; ph < 2; ++ph) {
+                if (ph == 1 && lim1 == lim2) break;
+                const int lo_p = ph == 0 ? left : left + lim1;
+                const int lim = ph == 0 ? left + lim1 : left + lim2;
+                auto flags = [&](int p, T v, bool& bl, bool& br) {
+                    const bool good = ph == 0 ? (v < cut) : (v <= cut);
+                    bl = p >= lo_p && p < lim && !good;
+                    br = p >= lim && good;
+                };
+                unsigned nl = 0, nr = 0;                  // wave-uniform
+#pragma unroll 1
+                for (int base = w0; base < w1; base += 64 * kFinBatch) {
+                    T v[kFinBatch];
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) { const int p = base + u * 64 + lane; v[u] = coord[4 * (size_t)min(p, w1 - 1)]; }
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) {
+                        const int p = base + u * 64 + lane;
+                        bool bl, br; flags(p, v[u], bl, br);
+                        nl += (unsigned)__popcll(__ballot(p < w1 && bl)); nr += (unsigned)__popcll(__ballot(p < w1 && br));
+                    }
+                }
+                if (lane == 0) { s_cnt[wave][0] = nl; s_cnt[wave][1] = nr; }
+                __syncthreads();
+                unsigned el = 0, er = 0, tl = 0, tr = 0;
+#pragma unroll
+                for (int w = 0; w < kFinThreads / 64; ++w) {
+                    const unsigned a = s_cnt[w][0], c2 = s_cnt[w][1];
+                    if (w < wave) { el += a; er += c2; }
+                    tl += a; tr += c2;
+                }
+#pragma unroll 1
+                for (int base = w0; base < w1; base += 64 * kFinBatch) {
+                    T v[kFinBatch];
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) { const int p = base + u * 64 + lane; v[u] = coord[4 * (size_t)min(p, w1 - 1)]; }
+#pragma unroll
+                    for (int u = 0; u < kFinBatch; ++u) {
+                        const int p = base + u * 64 + lane;
+                        bool bl, br; flags(p, v[u], bl, br);
+                        bl = bl && p < w1; br = br && p < w1;
+                        const unsigned long long ml = __ballot(bl), mr = __ballot(br);
+                        if (bl) b.BLpos[left + (int)(el + (unsigned)__popcll(ml & lower))] = p;
+                        if (br) b.BRpos[left + (int)(tr - 1 - (er + (unsigned)__popcll(mr & lower)))] = p;      // rank from the right end
+                        el += (unsigned)__popcll(ml); er += (unsigned)__popcll(mr);
+                    }
+                }
+                __syncthreads();
+                const int nbad = (int)tl;
+#pragma unroll 1
+                for (int base = tid; base < nbad; base += kFinThreads * 4) {
+                    int pl[4], pr[4]; Pt4<T> a[4], c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = min(base + u * kFinThreads, nbad - 1); pl[u] = b.BLpos[left + j]; pr[u] = b.BRpos[left + j]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = b.E[pl[u]]; c[u] = b.E[pr[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (base + u * kFinThreads < nbad) { b.E[pl[u]] = c[u]; b.E[pr[u]] = a[u]; }
+                }
+                __syncthreads();
+            }
+            // split index (middleSplit_ tail), the children, their tight boxes
+            int index;
+            if (lim1 > count / 2) index = lim1; else if (lim2 < count / 2) index = lim2; else index = count / 2;
+            if (tid == 0) { s_i[2] = atomicAdd(b.n_nodes, 2); atomicAdd(b.n_real, 2); atomicMax(b.max_depth, depth + 1); }
+            {
+                T lo[3], hi[3], lo2[3], hi2[3];
+                kd_fin_minmax2(b.E, left, left + index, right, lo, hi, lo2, hi2);
+                fold_mm(lo, hi, 0); fold_mm(lo2, hi2, 1);
+            }
+            T cb0[6], cb1[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { cb0[j] = bb[j]; cb1[j] = bb[j]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (j == f) { cb0[3 + j] = cut; cb1[j] = cut; }
+            __syncthreads();
+            finish_mm(2);
+            in_roi2(cb0, cb1);
+            __syncthreads();
+            const int c = s_i[2];
+            if (tid < 2) {
+                KdNode<T>& ch = b.nodes[c + tid];
+                kd_node_init(ch, tid ? left + index : left, tid ? right : left + index);
+                for (int j = 0; j < 3; ++j) { ch.bb_lo[j] = tid ? cb1[j] : cb0[j]; ch.bb_hi[j] = tid ? cb1[3 + j] : cb0[3 + j]; }
+                for (int j = 0; j < 3; ++j)
+                    if (s_mm[6 * tid + j] <= s_mm[6 * tid + 3 + j]) { ch.mm_lo[j] = enc(s_mm[6 * tid + j]); ch.mm_hi[j] = enc(s_mm[6 * tid + 3 + j]); }
+                ch.depth = depth + 1;
+                const int cnt = tid ? count - index : index;
+                if (cnt > b.leaf_max && !s_in[tid]) ch.active = 1;                                     // outside every region of interest: stub
+                else if (cnt <= b.sub_max) b.sub_nodes[atomicAdd(b.n_sub, 1)] = c + tid;             // finished in LDS later
+                else s_in[tid] = 2;                                                                    // goes on
+            }
+            if (tid == 0) { nd.divfeat = f; nd.cutval = cut; nd.lt = lim1; nd.le = lim2; nd.child1 = c; nd.child2 = c + 1; }
+            __syncthreads();
+            if (tid == 0) {
+                int sp = s_i[3];
+                const bool big_first = index >= count - index;          // the larger child is pushed first, the smaller is taken next
+                for (int k = 0; k < 2; ++k) {
+                    const int side = big_first ? k : 1 - k;
+                    if (s_in[side] != 2) continue;
+                    if (sp >= 64) __builtin_trap();                     // (cannot happen: the chain of "next" nodes at least halves)
+                    s_stack[sp++] = c + side;
+                }
+                s_i[3] = sp;
+            }
+            __syncthreads();
+            from_level = false;
+            const int sp = s_i[3];
+            if (sp == 0) break;
+            id = s_stack[sp - 1];
+            __syncthreads();
+            if (tid == 0) s_i[3] = sp - 1;
+            __syncthreads();
+        }
+    }
+}
+
 // ---- sub-trees in LDS -------------------------------------------------------------------------------------------------
 // One workgroup takes a node of <= S elements, copies the elements into LDS and runs the *same* level-by-level
 // algorithm there (choose / count / ranked misplaced lists / pairwise swap, twice / split / children boxes) with
@@ -425,8 +715,11 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     int* s_misc = reinterpret_cast<int*>(s_w + 40);                            // [0]=n_next [1]=id base [2]=loop-2 needed [3]=nodes created
     T* n_bb = reinterpret_cast<T*>(s_misc + 8);                                // [CAP][6] hand-down boxes of the active nodes
 
-    const int root_gid = b.sub_nodes[blockIdx.x];
     long long t_prev = b.prof ? wall_clock64() : 0;
+    // (the launcher may not know the list's length: without a host read-back it launches a fixed grid that strides over the list)
+    const int n_sub_nodes = *b.n_sub;
+    for (int si = blockIdx.x; si < n_sub_nodes; si += gridDim.x) {
+    const int root_gid = b.sub_nodes[si];
 #define KD_PROF(slot) do { if (b.prof && blockIdx.x == 0 && threadIdx.x == 0) { long long t_now = wall_clock64(); b.prof[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     KdNode<T>& root = b.nodes[root_gid];
     const int g0 = root.left, n = root.right - root.left;
@@ -668,6 +961,8 @@ __global__ __launch_bounds__(kSubThreads) void k_kd_subtree(KdBuild<T> b) {
     for (int p = tid; p < n; p += kSubThreads) b.E[g0 + p] = E[p];
     if (tid == 0 && s_misc[3]) atomicAdd(b.n_real, s_misc[3]);
     KD_PROF(7);
+    __syncthreads();
+    }
 #undef KD_PROF
 }
 

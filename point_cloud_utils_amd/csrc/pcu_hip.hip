@@ -98,7 +98,7 @@ struct pcu_hip_ctx {
     struct KdSpec {
         bool active = false;                  // a prefix for (pts, gp, m, leaf, with_ph2) is in flight or done and not yet adopted
         bool pending = false;                 // ev_done recorded and not yet waited for by a later user of the workspace
-        const void* pts = nullptr; const void* gp = nullptr; int m = 0, leaf = 0; bool with_ph2 = false; int pairs_done = 0;
+        const void* pts = nullptr; const void* gp = nullptr; int m = 0, leaf = 0; bool with_ph2 = false; int levels_done = 0;
         hipEvent_t ev_fork = nullptr, ev_init = nullptr, ev_done = nullptr;
     } kd_spec;
     bool kd_spec_hint = false;                // sticky: the last large k_nearest_neighbors call of this context had genuine ties
@@ -333,7 +333,12 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
     // The one-pass build's second form (grid2.h): k_bucket_onepass3 -> k_bucket_sort2, while the bucket tables fit beside the scatter's stage.
     // PCU_HIP_BUILD_V1=1 (and the diagnostics of the first form, PCU_HIP_GRID_KERNEL / PCU_HIP_PROF_BUILD) keep the round-3 chain below.
     static const bool build_v1 = getenv("PCU_HIP_BUILD_V1") != nullptr || getenv("PCU_HIP_PROF_BUILD") != nullptr;
-    if (grid_in_onepass && !build_v1 && ctx && ctx->fill2 && a.xpartial && (!b || b->xpartial) && a.nb_max <= kStagedMaxBuckets && (!b || b->nb_max <= kStagedMaxBuckets)) {
+    // A scatter block's (block, bucket) runs must stay long for the staged copies to pay: below ~12 records per run the padding to whole
+    // 8-record groups and the hole records the sort then reads cost more than the first form's per-record scatter (4M-point clouds:
+    // 0.40 ms against 0.285, config 3).
+    const int run_floor = 12 * std::max(a.nb_max, b ? b->nb_max : 0);
+    if (grid_in_onepass && !build_v1 && ctx && ctx->fill2 && a.xpartial && (!b || b->xpartial) && a.nb_max <= kStagedMaxBuckets && (!b || b->nb_max <= kStagedMaxBuckets) &&
+        kBkThreads * StagedPts<T>::n >= run_floor) {
         unsigned long long* const fw = ctx->fill2 + (size_t)ctx->fill_parity * kFillWords;
         unsigned long long* const fw_next = ctx->fill2 + (size_t)(ctx->fill_parity ^ 1) * kFillWords;
         ctx->fill_parity ^= 1;
@@ -798,6 +803,19 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
 // traversal (kd_order.h). Only called when the grid search reported genuine ties -- or ahead of need, see KdSpec.
 constexpr int kKdSpecPairs = 4;          // level pairs started early: the 8 top levels, which hold (nearly) all points whichever queries are tied
 constexpr int kKdSpecMinPoints = 262144;
+constexpr int kKdFinishGrid = 1024;       // workgroups of k_kd_finish (they stride over the level list)
+constexpr int kKdSubGridRoi = 256;        // workgroups of k_kd_subtree when the list's length is not read back
+static int kd_finish_max() {
+    static const int v = getenv("PCU_HIP_KD_FINISH_MAX") ? atoi(getenv("PCU_HIP_KD_FINISH_MAX")) : 16384;
+    return v;
+}
+template <typename T>
+static hipError_t kd_subtree_attr() {
+    static bool attr_set = false;
+    if (attr_set) return hipSuccess;
+    attr_set = true;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_subtree<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kd_sub_lds_bytes<T>());
+}
 template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
                            KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0,
@@ -842,6 +860,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // level are pure launch floor: the level graph is first replayed without them; if some node turns out to hold such
     // elements (device flag), the build is redone with them and the context remembers (duplicated points, lattices).
     int hcnt[16] = {0};
+    bool sub_launched = false;          // the LDS sub-trees were enqueued without a read-back of their count
     // whoever uses the workspace next waits for an earlier speculative prefix (adopted or not)
     if (sp.pending) { HIP_TRY(hipStreamWaitEvent(s, sp.ev_done, 0)); sp.pending = false; }
     bool adopt = !speculative && sp.active && sp.pts == (const void*)d_pts && sp.gp == (const void*)gp && sp.m == M && sp.leaf == leaf_max &&
@@ -849,10 +868,10 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     if (!speculative) sp.active = false;
     for (int rebuild = 0; rebuild < 2; ++rebuild) {
     const bool with_ph2 = c->kd_need_ph2;
-    int pairs_done = 0;
+    int levels_done = 0;
     if (adopt && rebuild == 0) {
         // the top levels are there (built without regions of interest: complete); the regions apply from here on
-        pairs_done = sp.pairs_done;
+        levels_done = sp.levels_done;
         static const bool no_roi = getenv("PCU_HIP_KD_FULL") != nullptr;
         if (roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && !no_roi)
             hipLaunchKernelGGL(k_kd_roi<T>, dim3(1), dim3(kKdMaxRoi), 0, s, roi_job->qidx.sorted, roi_job->sc.tt, n_tied, roi_job->out_d, roi_job->k,
@@ -876,23 +895,29 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // lists has period 2) are captured ONCE into a hipGraph and replayed: the expected log2(M / sub_max) + 2
     // levels first, then two at a time until the device reports an empty level. Replay removes most of the
     // per-launch host cost, which dominated this launch-bound phase.
-    auto enqueue_level_pair = [&](KdBuild<T> bb, bool with_ph2) {
-        for (int half = 0; half < 2; ++half) {
-            hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
-            hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
-            for (int ph = 0; ph < (with_ph2 ? 2 : 1); ++ph) {
-                hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
-                hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
-                hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
-            }
-            hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, bb);
-            std::swap(bb.level_nodes, bb.next_nodes);
-            std::swap(bb.level_cbase, bb.next_cbase);
-            std::swap(bb.n_cur, bb.n_next);
+    auto enqueue_one_level = [&](KdBuild<T>& bb, bool with_ph2) {           // (leaves bb with the roles of the two level lists exchanged)
+        hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
+        hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
+        for (int ph = 0; ph < (with_ph2 ? 2 : 1); ++ph) {
+            hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+            hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+            hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
         }
+        hipLaunchKernelGGL(k_kd_advance<T>, dim3(1), dim3(kBlock), 0, s, bb);
+        std::swap(bb.level_nodes, bb.next_nodes);
+        std::swap(bb.level_cbase, bb.next_cbase);
+        std::swap(bb.n_cur, bb.n_next);
     };
+    auto enqueue_level_pair = [&](KdBuild<T> bb, bool with_ph2) { enqueue_one_level(bb, with_ph2); enqueue_one_level(bb, with_ph2); };
     int expected = 2;
     for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
+    // Level passes only while the nodes are large: below kd_finish_max() elements one workgroup per node finishes the rest
+    // (k_kd_finish). 0 = level passes all the way down to the LDS sub-trees (the round-3 flow).
+    const int fin_max = kd_finish_max();
+    int levels_sync = 0;
+    if (fin_max > 0) for (long long m = M; m > fin_max; m = (m + 1) >> 1) ++levels_sync;
+    const bool roi_mode = !speculative && roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && getenv("PCU_HIP_KD_FULL") == nullptr;
+    sub_launched = false;
     if (M > b.sub_max) {
         auto& G = c->kd_graph[(sizeof(T) == 4 ? 0 : 2) + (with_ph2 ? 1 : 0)];
         const bool use_graph = getenv("PCU_HIP_NO_GRAPH") == nullptr && s != nullptr;      // (the legacy NULL stream cannot be captured: eager launches there)
@@ -905,16 +930,44 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
             G.key_ptr = (const void*)b.E; G.key_m = M; G.key_leaf = leaf_max;
         }
+        // levels [from, to): pairs replay the graph (after an even number of levels the two level lists have their original roles), an
+        // odd level is enqueued directly; `cur` ends as the build with the roles the next consumer must see
+        KdBuild<T> cur = b;
+        auto run_levels = [&](int from, int to) -> int {
+            if (from & 1) { std::swap(cur.level_nodes, cur.next_nodes); std::swap(cur.level_cbase, cur.next_cbase); std::swap(cur.n_cur, cur.n_next); }
+            for (int done = from; done < to;) {
+                if (!(done & 1) && to - done >= 2) { if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(cur, with_ph2); done += 2; }
+                else { enqueue_one_level(cur, with_ph2); done += 1; }
+            }
+            return 0;
+        };
         if (speculative) {
-            const int np = std::min(kKdSpecPairs, (expected + 1) / 2);
-            for (int i = 0; i < np; ++i) { if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2); }
+            const int nl = fin_max > 0 ? std::min(2 * kKdSpecPairs, levels_sync) : 2 * std::min(kKdSpecPairs, (expected + 1) / 2);
+            if (run_levels(0, nl)) return -1;
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(sp.ev_done, s));
             sp.active = true; sp.pending = true; sp.pts = (const void*)d_pts; sp.gp = (const void*)gp; sp.m = M; sp.leaf = leaf_max;
-            sp.with_ph2 = with_ph2; sp.pairs_done = np;
+            sp.with_ph2 = with_ph2; sp.levels_done = nl;
             return 0;
         }
-        int pairs = std::max(1, (expected + 1) / 2 - pairs_done);
+        if (fin_max > 0) {
+            if (run_levels(levels_done, std::max(levels_done, levels_sync))) return -1;
+            hipLaunchKernelGGL(k_kd_finish<T>, dim3(kKdFinishGrid), dim3(kFinThreads), 0, s, cur);
+            HIP_TRY(hipGetLastError());
+            if (roi_mode) {
+                // few nodes are alive: the LDS sub-trees follow without a host read-back of their count (a fixed grid strides over the
+                // list); a top level that met elements equal to its cut value without the second planeSplit loop is reported through
+                // the counters the caller reads with the traversal's error flag (tie_order_resolve)
+                HIP_TRY(kd_subtree_attr<T>());
+                hipLaunchKernelGGL(k_kd_subtree<T>, dim3(kKdSubGridRoi), dim3(kSubThreads), kd_sub_lds_bytes<T>(), s, b);
+                HIP_TRY(hipGetLastError());
+                sub_launched = true;
+            } else {
+                HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+        } else {
+        int pairs = std::max(1, (expected + 1) / 2 - levels_done / 2);
         for (int guard = 0; guard < 100000; ++guard) {
             for (int i = 0; i < pairs; ++i) {
                 if (use_graph) HIP_TRY(hipGraphLaunch(G.exec, s)); else enqueue_level_pair(b, with_ph2);
@@ -925,9 +978,10 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             if (hcnt[b.n_cur - counters] == 0) break;      // after an even number of levels the roles are as at the start
             pairs = 1;
         }
+        }
     }
     if (speculative) return 0;          // (a tree small enough for the LDS sub-tree kernel alone: nothing to start early)
-    if (!with_ph2 && hcnt[9]) { c->kd_need_ph2 = true; continue; }
+    if (!with_ph2 && hcnt[9] && !sub_launched) { c->kd_need_ph2 = true; continue; }
     break;
     }
     (void)c;
@@ -936,14 +990,9 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    const int n_sub = hcnt[4];
+    const int n_sub = sub_launched ? 0 : hcnt[4];
     if (n_sub > 0) {
-        static bool attr_set[2] = {false, false};
-        const int ti = sizeof(T) == 4 ? 0 : 1;
-        if (!attr_set[ti]) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_subtree<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kd_sub_lds_bytes<T>()));
-            attr_set[ti] = true;
-        }
+        HIP_TRY(kd_subtree_attr<T>());
         hipLaunchKernelGGL(k_kd_subtree<T>, dim3(n_sub), dim3(kSubThreads), kd_sub_lds_bytes<T>(), s, b);
         HIP_TRY(hipGetLastError());
     }
@@ -1018,9 +1067,14 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         a.stack = frames;
         hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
         HIP_TRY(hipGetLastError());
-        int herr = 0;
-        HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+        int hc[16] = {0};                  // the build's counters: [3] = the traversal's error flag, [9] = a node held elements equal to its cut value
+        HIP_TRY(hipMemcpyAsync(hc, err - 3, sizeof hc, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (hc[9] && !c->kd_need_ph2) {     // top levels ran without planeSplit's second loop and needed it (kd_build_device, regions of
+            c->kd_need_ph2 = true;          // interest: no read-back before the traversal): once more, the context remembers
+            --attempt; continue;
+        }
+        int herr = hc[3];
         if (herr == 1 && lazy) {            // deeper than the bound: once more with the exact depth
             int depth = 0;
             HIP_TRY(hipMemcpy(&depth, depth_dev, sizeof(int), hipMemcpyDeviceToHost));
@@ -2283,7 +2337,16 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    {   // The second stream carries the speculative top of the tie-order tree beside a call's searches: short, latency-bound passes that
+        // the critical path waits for once the searches are done. At the highest priority they get the slots the lane kernel frees
+        // first instead of last (config 3: the tree top ended 0.36 ms after the searches, PCU_HIP_AUX_PRIORITY=0 for the default).
+        int lo_p = 0, hi_p = 0;
+        const char* e = getenv("PCU_HIP_AUX_PRIORITY");
+        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hi_p != lo_p)
+            HIP_TRY(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    }
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));

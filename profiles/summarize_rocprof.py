@@ -19,7 +19,7 @@ def main(path, json_out=None):
     for name, calls, tot, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         print(f"{name[:100]:100s} {calls:6d} {tot/1:12.1f} {avg:10.2f} {pct:6.2f}")
     rows = list(cur.execute("select name, start, end, grid_x from kernels order by start"))
-    starts = [i for i, r in enumerate(rows) if "k_bbox_partial" in r[0] or "k_prep" in r[0]]          # first kernel of every step
+    starts = [i for i, r in enumerate(rows) if "k_bbox_partial" in r[0] or "k_bucket_onepass3" in r[0]]          # first kernel of every step
     if len(starts) >= 8:
         a = starts[len(starts) // 2 + 1]
         b = starts[len(starts) // 2 + 3]
