@@ -73,6 +73,7 @@ static HostProf g_hprof;
 struct pcu_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t spec_stream = nullptr;         // the speculative tie-order tree top (see pcu_hip_ctx_create)
     hipStream_t aux_stream = nullptr;          // second lane for two-sided ops: the two clouds' index builds and the two
                                                // search directions are independent and latency-bound, so they overlap
     hipEvent_t jev[4] = {};                    // fork/join events between the caller's stream and aux_stream
@@ -94,7 +95,7 @@ struct pcu_hip_ctx {
     struct KdGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; const void* key_ptr = nullptr; long long key_m = 0; int key_leaf = 0; } kd_graph[4];   // [type][with second planeSplit loop]
     bool kd_need_ph2 = false;                 // sticky: this context has seen data with elements equal to a cut value
     // Speculative tree top (kd_build_device, mode 1): a call whose predecessor needed the tie-order resolver starts the top levels of
-    // the tree -- which do not depend on which queries are tied -- on aux_stream while the searches run; the resolver adopts them.
+    // the tree -- which do not depend on which queries are tied -- on spec_stream while the searches run; the resolver adopts them.
     struct KdSpec {
         bool active = false;                  // a prefix for (pts, gp, m, leaf, with_ph2) is in flight or done and not yet adopted
         bool pending = false;                 // ev_done recorded and not yet waited for by a later user of the workspace
@@ -820,10 +821,10 @@ template <typename T>
 static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_pts, int M, const GridParams<T>* gp, int leaf_max,
                            KdBuild<T>& b, int** err_out, int* levels_out, int* n_real_out, const SearchJob<T>* roi_job = nullptr, int n_tied = 0,
                            bool speculative = false, bool need_depth = true, int** max_depth_out = nullptr) {
-    // speculative: only the first kKdSpecPairs level pairs, on c->aux_stream behind the event c->kd_spec.ev_fork (recorded by the caller
+    // speculative: only the first kKdSpecPairs levels, on c->spec_stream behind the event c->kd_spec.ev_fork (recorded by the caller
     // on its stream once gp is final), no host synchronisation; a later normal call for the same input continues from there.
     pcu_hip_ctx::KdSpec& sp = c->kd_spec;
-    if (speculative) s = c->aux_stream;
+    if (speculative) s = c->spec_stream;
     b.leaf_max = leaf_max;
     b.sub_max = (int)std::min<long long>(KdSub<T>::S, (long long)KdSub<T>::CAP * (leaf_max + 1));
     // level lists only ever hold nodes with more than sub_max elements
@@ -2337,15 +2338,16 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    {   // The second stream carries the speculative top of the tie-order tree beside a call's searches: short, latency-bound passes that
-        // the critical path waits for once the searches are done. At the highest priority they get the slots the lane kernel frees
-        // first instead of last (config 3: the tree top ended 0.36 ms after the searches, PCU_HIP_AUX_PRIORITY=0 for the default).
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    {   // The speculative top of the tie-order tree runs beside a call's searches on a stream of its own. PCU_HIP_SPEC_PRIORITY=1 gives it the
+        // highest stream priority: the tree top then ends 0.12 ms after config 3's searches instead of 0.3 -- but the mere existence of a
+        // prioritised stream in the process slows calls that alternate two ordinary streams (config 4: 1.41 -> 1.9-2.1 ms), so it is off.
         int lo_p = 0, hi_p = 0;
-        const char* e = getenv("PCU_HIP_AUX_PRIORITY");
-        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hi_p != lo_p)
-            HIP_TRY(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi_p));
+        const char* e = getenv("PCU_HIP_SPEC_PRIORITY");
+        if (e && atoi(e) != 0 && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hi_p != lo_p)
+            HIP_TRY(hipStreamCreateWithPriority(&c->spec_stream, hipStreamNonBlocking, hi_p));
         else
-            HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&c->spec_stream, hipStreamNonBlocking));
     }
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -2379,6 +2381,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->spec_stream) (void)hipStreamDestroy(c->spec_stream);
     for (auto& e : c->jev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
