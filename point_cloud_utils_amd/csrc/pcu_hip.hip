@@ -659,7 +659,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.qlist2 = nullptr; a.qcount2_dev = nullptr; a.R2 = 0; a.row_out = j.row_out ? 1 : 0;
     a.out_d = j.out_d; a.out_i = j.out_i;
     a.unresolved = nullptr; a.n_unresolved = nullptr; a.ties = nullptr; a.n_ties = nullptr; a.ubound = nullptr; a.qbound2 = nullptr;
-    a.skew_limit = 0.f; a.skew_lo = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
+    a.skew_limit = 0.f; a.skew_far = 3.0e38f; a.skew_lo = 0.f; a.skew_flag = j.sc.counters + C_SKEW;      // only the first whole-cloud pass checks the balance
     a.qgp = j.qidx.gp;
     // unbalanced clouds (finer sub-box levels exist): a lane next to a heavy cell would scan thousands of candidates serially and hold its
     // wave for hundreds of microseconds (10 % cluster cloud: the base-grid lane pass took 380 us for 0.9M queries) -- hand such queries to
@@ -709,7 +709,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
             a.ties = sc.t1; a.n_ties = sc.counters + C_T1;
             if (!last) { a.ties = j.fine_ties[lv]; a.n_ties = sc.counters + C_TF0 + lv; }
             // balance limit: mean number of cell mates (sumsq / n) above kSkewFactor x the Poisson value (occupancy + 1)
-            if (last && j.skew_check && j.n_fine == 0) { a.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
+            if (last && j.skew_check && j.n_fine == 0) { a.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a.skew_far = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n); a.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
             const bool time_it = st && c->time_kernels && lv == 0 && c->n_kev + 2 <= 8;
             if (time_it) (void)hipEventRecord(c->kev[c->n_kev], s);
             if (launch_search_fast<T>(KF, a, j.qidx.n, s, /*open_index=*/last)) return -1;
@@ -740,7 +740,7 @@ static int search_enqueue(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j, 
         if (j.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue on a wave-only search");
         b.qlist = nullptr; b.qcount_dev = nullptr; b.nq = j.qidx.n; b.R = 1;     // every query, radius 1, total order
         b.unresolved = sc.u1; b.n_unresolved = sc.counters + C_U1;
-        if (j.skew_check) { b.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); b.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
+        if (j.skew_check) { b.skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); b.skew_far = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n); b.skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
         if (launch_search_wave<T>(KL, b, s)) return -1;
         b.nq = 0; b.skew_limit = 0.f; b.skew_lo = 0.f;
         b.qlist = sc.u1; b.qcount_dev = sc.counters + C_U1; b.R = 2;             // stragglers, radius 2
@@ -777,7 +777,7 @@ static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>
         a[d].nq = j.qidx.n; a[d].R = 1;
         a[d].unresolved = sc.u1; a[d].n_unresolved = sc.counters + C_U1; a[d].ubound = sc.ub1;
         a[d].ties = sc.t1; a[d].n_ties = sc.counters + C_T1;
-        if (j.skew_check) { a[d].skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a[d].skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
+        if (j.skew_check) { a[d].skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); a[d].skew_far = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n); a[d].skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
         b[d] = base_args(j, j.ridx);
         b[d].ties = sc.tt; b[d].n_ties = sc.counters + C_TT;
         b[d].qlist = sc.t1; b[d].qcount_dev = sc.counters + C_T1; b[d].R = 1;            // possible ties -> total order, radius 1
@@ -1106,8 +1106,10 @@ static void job_rescale_setup(const pcu_hip_ctx* c, SearchJob<T>& j, bool allowe
 // A pass gave up on the balance check: is it a case for a different grid resolution (then c->occ_scale is updated and the caller
 // restarts the call) or for the refit machinery (false)?
 template <typename T>
-static bool rescale_wanted(pcu_hip_ctx* c, const SearchJob<T>& j, hipStream_t s) {
+static bool rescale_wanted(pcu_hip_ctx* c, const SearchJob<T>& j, hipStream_t s, int skew_flag) {
     if (!j.may_rescale) return false;
+    // flag value 2 (search.h, skew_far): unbalanced beyond kSkewFactor -- a case for the refit path whatever the exact ratio is
+    if (skew_flag == 2 && c->occ_scale[j.role] >= 1.0) return false;
     GridParams<T> hg;
     if (hipMemcpyAsync(&hg, j.ridx.gp, sizeof hg, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
     const double r = (double)hg.sumsq / (double)j.ridx.n / (j.occ + 1.0);
@@ -1143,8 +1145,28 @@ static int nonfinite_error(bool metric) {
 // (host-driven, one sync per pass; only far-away / isolated queries ever get here).
 // Returns 1 if extra passes ran (callers then redo dependent reductions), 0 if not, 3 if the call is to be restarted (rescale_wanted),
 // <0 on error.
+// Two sub-box levels over the heavy cells (more than 8x the wanted occupancy) of `from`, and once more over what is still heavy in the
+// first (tight clusters inside blobs); the passes then run finest level first.
 template <typename T>
-static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc) {
+static int skew_add_levels(Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const GridIndex<T>& from, const double** hs_dev) {
+    const unsigned thresh = (unsigned)(8.0 * j.occ + 8.0);
+    GridIndex<T> sub1, sub2;
+    if (index_build_heavy(ar, sub1, from, j.d_ref_pts, j.occ, thresh, s, hs_dev)) return -1;
+    if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
+    if (st) st->n_grid_builds += 2;
+    j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
+    for (int lv = 0; lv < 2; ++lv) if (!j.fine_ties[lv] && aalloc(ar, &j.fine_ties[lv], (size_t)j.qidx.n)) return -1;
+    return 0;
+}
+// A direction's refit attempt enqueued ahead of search_finish (skew_prelaunch: both directions of a two-sided call at once, on two
+// streams), with what its read-backs delivered.
+struct SkewPre {
+    bool on = false;
+    int hc_redo[C_N]; double hs[2] = {0, 0}; const double* hs_dev = nullptr;
+    int d_passes = 0, d_builds = 0;             // what the attempt added to the call's statistics (taken back if it is dropped)
+};
+template <typename T>
+static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, const int* hc, SkewPre* pre = nullptr) {
     // hc: host copy of j.sc.counters, read back by the caller together with the call's scalar results
     // (one D2H copy + one stream sync for the whole call in the common case)
     int hc_redo[C_N], hc_large[C_N];
@@ -1170,17 +1192,17 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         HIP_TRY(hipStreamSynchronize(s));
         hc = hc_large; redone = true;
     }
-    if (hc[C_SKEW] && rescale_wanted(c, j, s)) return 3;          // 3: restart the call at another grid resolution
+    if (hc[C_SKEW] && rescale_wanted(c, j, s, hc[C_SKEW])) return 3;          // 3: restart the call at another grid resolution
     if (hc[C_SKEW]) {
         // The dataset grid is badly unbalanced (clusters, blobs, a far outlier inflating the bbox): every pass gave up
         // at once. Refit: same cell count over the core range of the cloud (replaces `ridx`), then up to two finer
         // grids sized by how unbalanced the previous one still is; the passes then run finest grid first.
+        if (!(pre && pre->on))
         index_large_pass<T>(j.qidx, &j.ridx, s);        // (the balance check comes first in the kernels: unplaced over-full buckets
                                                         // of the query index would stop the passes below as well)
         // heavy cells (more than 8x the wanted occupancy): a sub-box grid over them, sized by how overfull they are;
         // and once more over what is still heavy in that one (tight clusters inside blobs)
-        const unsigned thresh = (unsigned)(8.0 * j.occ + 8.0);
-        GridIndex<T> base, sub1, sub2;
+        GridIndex<T> base;
         GridParams<T> hb;
         // First on the grid as built: its range is already the robust one (grid.h: make_grid_body clips at 3 sigma), so a cloud that
         // is uneven because of clusters keeps it and only gains the sub-box levels -- tight-cluster Chamfer at 1M: 2 x (125 us of
@@ -1188,16 +1210,15 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         // stretched even the clipped range: the grid itself is useless) is the base refitted to the cloud's core range first.
         static const bool always_refit = getenv("PCU_HIP_REFIT_BASE") != nullptr;
         bool keep_base = !always_refit;
-        auto add_levels = [&](const GridIndex<T>& from, const double** hs_dev) -> int {
-            if (index_build_heavy(ar, sub1, from, j.d_ref_pts, j.occ, thresh, s, hs_dev)) return -1;
-            if (index_build_heavy(ar, sub2, sub1, j.d_ref_pts, j.occ, thresh, s)) return -1;
-            if (st) st->n_grid_builds += 2;
-            j.fine[0] = sub2; j.fine[1] = sub1; j.n_fine = 2;
-            for (int lv = 0; lv < 2; ++lv) if (!j.fine_ties[lv] && aalloc(ar, &j.fine_ties[lv], (size_t)j.qidx.n)) return -1;
-            return 0;
-        };
+        auto add_levels = [&](const GridIndex<T>& from, const double** hs_dev) -> int { return skew_add_levels(ar, s, j, st, from, hs_dev); };
         j.skew_check = false;
-        if (keep_base) {
+        if (keep_base && pre && pre->on) {
+            // enqueued and read back by the caller (skew_prelaunch), together with the other direction's
+            memcpy(hc_redo, pre->hc_redo, sizeof hc_redo);
+            keep_base = pre->hs[1] <= 0.5 * (double)j.ridx.n;
+            if (!keep_base && st) { st->n_passes -= pre->d_passes; st->n_grid_builds -= pre->d_builds; }
+            if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d heavy points %.0f, level cells %.0f: %s (both directions enqueued together)\n", j.ridx.n, pre->hs[1], pre->hs[0], keep_base ? "grid kept" : "base refit");
+        } else if (keep_base) {
             // everything enqueued at once -- both sub-box levels, the passes, the read-back of the heavy-cell statistics next to the counters:
             // ONE host round trip for the direction (the balance metric that brought us here, > 32 x the even value, already says that
             // levels are needed). If the statistics then say "base refit", what was enqueued is dropped.
@@ -1721,7 +1742,7 @@ template <typename T>
 static bool fused_rescale(pcu_hip_ctx* c, hipStream_t s, const PairState<T>& P, const ResultBlock& h) {
     bool want = false;
     for (int d = 0; d < (P.two ? 2 : 1) && !want; ++d)
-        if (h.counters[d][C_SKEW]) want = rescale_wanted(c, d ? P.yx : P.xy, s);
+        if (h.counters[d][C_SKEW]) want = rescale_wanted(c, d ? P.yx : P.xy, s, h.counters[d][C_SKEW]);
     return want;
 }
 // A fused attempt whose only flaw is that some queries are still uncertified after radius 2 (sparse tails, outliers): finish
@@ -1797,6 +1818,27 @@ static bool skewed_everywhere(const PairState<T>& P, const ResultBlock& h) {
     for (int d = 0; d < (P.two ? 2 : 1); ++d) if (!h.counters[d][C_SKEW] || h.counters[d][C_LARGE]) return false;
     return true;
 }
+// The first step of search_finish's refit path (levels over the grid as built + the passes + the read-backs), enqueued without the
+// host round trip, when the direction's counters say that this is what search_finish would do first.
+template <typename T>
+static bool skew_prelaunch_wanted(const pcu_hip_ctx* c, const SearchJob<T>& j, const int* hc) {
+    static const bool off = getenv("PCU_HIP_REFIT_BASE") != nullptr || getenv("PCU_HIP_NO_SKEW_OVERLAP") != nullptr;
+    return !off && !hc[C_LARGE] && hc[C_SKEW] && (!j.may_rescale || (hc[C_SKEW] == 2 && c->occ_scale[j.role] >= 1.0)) && !c->time_phases && !c->time_kernels;
+}
+template <typename T>
+static int skew_prelaunch(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, SkewPre& pre) {
+    const int p0 = st ? st->n_passes : 0, b0 = st ? st->n_grid_builds : 0;
+    index_large_pass<T>(j.qidx, &j.ridx, s);
+    j.skew_check = false;
+    const double* hs_dev = nullptr;
+    if (skew_add_levels(ar, s, j, st, j.ridx, &hs_dev)) return -1;
+    if (search_enqueue(c, s, j, st)) return -1;
+    pre.hs_dev = hs_dev;                         // (read back by the caller once BOTH directions are enqueued: a copy to pageable memory blocks the host)
+    pre.on = true;
+    if (st) { pre.d_passes = st->n_passes - p0; pre.d_builds = st->n_grid_builds - b0; }
+    return 0;
+}
+
 // Sync + finish stragglers. Returns 1 if the epilogue must be re-enqueued, 0 if not, 3 if the call is to be restarted, <0 on error.
 template <typename T>
 static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false,
@@ -1805,9 +1847,29 @@ static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P
     else if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
     else if (wait_result_block(c, s)) return -1;
     if (!host_given) memcpy(host, c->h_pinned, sizeof(ResultBlock));
-    int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0]);
+    // Both directions unbalanced (clustered clouds): their refits -- dozens of short launches each -- are enqueued side by side on the
+    // context's two streams and share ONE host round trip, instead of one direction after the other (round 3: 2 x 0.8 ms).
+    SkewPre pre[2];
+    if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[pair_finish] two=%d wanted=%d,%d (skew %d,%d large %d,%d may %d,%d scale %.2f,%.2f time %d%d)\n", (int)P.two, (int)skew_prelaunch_wanted(c, P.xy, host->counters[0]), (int)skew_prelaunch_wanted(c, P.yx, host->counters[1]), host->counters[0][C_SKEW], host->counters[1][C_SKEW], host->counters[0][C_LARGE], host->counters[1][C_LARGE], (int)P.xy.may_rescale, (int)P.yx.may_rescale, c->occ_scale[0], c->occ_scale[1], (int)c->time_phases, (int)c->time_kernels);
+    if (P.two && skew_prelaunch_wanted(c, P.xy, host->counters[0]) && skew_prelaunch_wanted(c, P.yx, host->counters[1])) {
+        HIP_TRY(hipEventRecord(c->jev[0], s));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->jev[0], 0));
+        if (skew_prelaunch(c, ar, s, P.xy, st, pre[0]) || skew_prelaunch(c, ar, c->aux_stream, P.yx, st, pre[1])) return -1;
+        HIP_TRY(hipEventRecord(c->jev[1], c->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(s, c->jev[1], 0));
+        // (into pinned memory: four copies in flight and one wait, instead of four blocking copies to pageable memory)
+        static_assert(2 * (sizeof(double) * 2 + sizeof(int) * C_N) <= 64 * sizeof(int), "pair_finish's read-backs fit the second half of h_pinned");
+        char* const hp = reinterpret_cast<char*>(c->h_pinned + 64);
+        for (int d = 0; d < 2; ++d) {
+            HIP_TRY(hipMemcpyAsync(hp + 16 * d, pre[d].hs_dev, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(hp + 32 + sizeof(int) * C_N * d, (d ? P.yx : P.xy).sc.counters, sizeof(int) * C_N, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int d = 0; d < 2; ++d) { memcpy(pre[d].hs, hp + 16 * d, 16); memcpy(pre[d].hc_redo, hp + 32 + sizeof(int) * C_N * d, sizeof(int) * C_N); }
+    }
+    int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0], &pre[0]);
     if (r1 < 0 || r1 == 3) return r1;
-    int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1]) : 0;
+    int r2 = P.two ? search_finish(c, ar, s, P.yx, st, host->counters[1], &pre[1]) : 0;
     if (r2 < 0 || r2 == 3) return r2;
     return (r1 | r2) ? 1 : 0;       // (2 = "only tied rows changed" matters to k_nearest_neighbors only)
 }
@@ -2352,8 +2414,8 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     for (auto& e : c->jev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->kev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into it
-    memset(c->h_pinned, 0, 64 * sizeof(int));
+    HIP_TRY(hipHostMalloc((void**)&c->h_pinned, 128 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // kernels write the result block into the first 64 words; [64, 128): pair_finish's read-backs
+    memset(c->h_pinned, 0, 128 * sizeof(int));
     HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
     HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
     HIP_TRY(hipMalloc((void**)&c->fill2, 2 * (size_t)kFillWords * sizeof(unsigned long long)));

@@ -50,6 +50,7 @@ struct SearchArgs {
     unsigned lane_max_cand;         // a lane whose 27 cells hold more candidates than this hands its query to the wave-per-query
                                     // pass (via the tie list) instead of scanning them serially: one heavy cell next to a query
                                     // must not turn a wave into a millisecond-long pole
+    float skew_far;                 // the flag's value is 2 instead of 1 when sumsq > skew_far (far beyond a change of resolution: the host then skips a read-back)
     float skew_limit;               // > 0: a whole-cloud pass gives up at once when the uniform dataset grid is unbalanced
     int* skew_flag;                 //      beyond this (sumsq > limit) and raises the flag; the host then refits the dataset grid (pcu_hip.hip, search_finish)
     float skew_lo;                  //      ... or when it is MORE even than this (sumsq < skew_lo; 0 = off): a grid kept finer than the default for
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
     const int qpos = active ? (a.qlist ? a.qlist[t] : t) : 0;
     const Pt4<T> q = a.qsorted[qpos];
     if (const int hl = index_not_ready(a, g)) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
-    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = (float)g.sumsq > a.skew_far ? 2 : 1; return; }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     // A closed sub-box level (dense part of an unbalanced cloud) can never certify a query outside its box [org, org + G h) --
     // face_lower_bound is then at most the query's distance to the level's points, which no candidate beats -- so such a query goes to
@@ -631,7 +632,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     if (vb * kBlock >= nq) return;                     // (block-uniform)
     const GridParams<T>& g = *a.gp;
     if (const int hl = index_not_ready(a, g)) { if (vb == 0 && tid == 0) a.skew_flag[kLargeFlag] = hl; return; }
-    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (vb == 0 && tid == 0) *a.skew_flag = 1; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (vb == 0 && tid == 0) *a.skew_flag = (float)g.sumsq > a.skew_far ? 2 : 1; return; }
     const int t = vb * kBlock + tid;
     if (t >= nq) return;
     constexpr bool valid = true;
@@ -937,8 +938,8 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     const int hl0 = index_not_ready(a0, *a0.gp), hl1 = index_not_ready(a1, *a1.gp);
     int total0 = (a0.qcount_dev ? v00 : a0.nq) + (a0.qlist2 ? v01 : 0);
     int total1 = njobs > 1 ? (a1.qcount_dev ? v10 : a1.nq) + (a1.qlist2 ? v11 : 0) : 0;
-    if (a0.skew_limit > 0.f && ((float)ss0 > a0.skew_limit || (float)ss0 < a0.skew_lo)) { if (wave == 0 && lane == 0) *a0.skew_flag = 1; total0 = 0; }
-    if (njobs > 1 && a1.skew_limit > 0.f && ((float)ss1 > a1.skew_limit || (float)ss1 < a1.skew_lo)) { if (wave == 0 && lane == 0) *a1.skew_flag = 1; total1 = 0; }
+    if (a0.skew_limit > 0.f && ((float)ss0 > a0.skew_limit || (float)ss0 < a0.skew_lo)) { if (wave == 0 && lane == 0) *a0.skew_flag = (float)ss0 > a0.skew_far ? 2 : 1; total0 = 0; }
+    if (njobs > 1 && a1.skew_limit > 0.f && ((float)ss1 > a1.skew_limit || (float)ss1 < a1.skew_lo)) { if (wave == 0 && lane == 0) *a1.skew_flag = (float)ss1 > a1.skew_far ? 2 : 1; total1 = 0; }
     if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = hl0; total0 = 0; }
     if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = hl1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
