@@ -154,7 +154,12 @@ def test_squeeze_of_singleton_shapes(pcu):
 SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINUE=1", "PCU_HIP_NO_SPIN=1", "PCU_HIP_NO_GRAPH=1",
             "PCU_HIP_NO_KD_SPEC=1", "PCU_HIP_NO_RESCALE=1", "PCU_HIP_KD_FULL=1", "PCU_HIP_NO_K1=1", "PCU_HIP_INDEX=atomic",
             "PCU_HIP_SINK_TWO_PASS=1", "PCU_HIP_DEBUG_SKEW=1", "PCU_HIP_NO_ESCALATE=1", "PCU_HIP_GRID_KERNEL=1", "PCU_HIP_REFIT_BASE=1",
-            "PCU_HIP_PROF_BUILD=1", "PCU_HIP_PROF_KD=1"]
+            "PCU_HIP_PROF_BUILD=1", "PCU_HIP_PROF_KD=1",
+            # round 4: first form of the one-pass build, Pt4 records for k = 1, cell-order rows + restore for k < 4, wave pass up front in
+            # fused calls, level passes all the way down / one workgroup for the whole tie-order tree, refits one direction at a time
+            "PCU_HIP_BUILD_V1=1", "PCU_HIP_NO_LEAN=1", "PCU_HIP_ROW_OUT_MIN_K=4", "PCU_HIP_FUSED_WAVE=1", "PCU_HIP_KD_FINISH_MAX=0",
+            "PCU_HIP_KD_FINISH_MAX=1000000000", "PCU_HIP_NO_SKEW_OVERLAP=1", "PCU_HIP_SPEC_PRIORITY=1", "PCU_HIP_PROF_BUILD2=1",
+            "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255"]
 
 
 @pytest.mark.gpu
