@@ -41,6 +41,9 @@ struct KdNode {
     T cutval;
     T bb_lo[3], bb_hi[3];                // the bbox handed DOWN to divideTree (input to middleSplit_)
     typename EncT<T>::type mm_lo[3], mm_hi[3];   // tight min/max of the node's points (encoded, atomics); = computeMinMax
+    typename EncT<T>::type cmm_lo[2][3], cmm_hi[2][3];   // tight boxes of {< cutval} and {>= cutval}, gathered by the count pass: the children's
+                                         // boxes when no element equals the cut value (then the children are exactly these two sets)
+    int mm_ready;                        // mm_lo / mm_hi were installed by the parent's level (k_kd_advance): k_kd_minmax has nothing to do
     int lt, le;                          // # elements < cutval, <= cutval
     int nbad[2];                         // misplaced pairs in planeSplit loop 1 / loop 2
     int chunk_base, nchunks;
@@ -71,6 +74,7 @@ struct KdBuild {
     // INSIDE a stub would be undefined -- and there are none, the tied points are inside the balls. *n_roi == 0: build all.
     const T* roi; const int* n_roi;
     int* need_ph2;                       // set when some node has elements equal to its cut value (planeSplit's second loop has work)
+    int* level_ph2;                      // the same for the level in flight (reset by k_kd_advance): loop 2's three launches exit at once when it is 0
 };
 
 template <typename T>
@@ -121,6 +125,8 @@ template <typename T>
 __device__ __forceinline__ void kd_node_init(KdNode<T>& nd, int left, int right) {
     nd.left = left; nd.right = right; nd.child1 = nd.child2 = -1; nd.divfeat = 0; nd.active = 0; nd.cutval = 0;
     for (int j = 0; j < 3; ++j) { nd.mm_lo[j] = ~(typename EncT<T>::type)0; nd.mm_hi[j] = 0; }
+    for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) { nd.cmm_lo[k][j] = ~(typename EncT<T>::type)0; nd.cmm_hi[k][j] = 0; }
+    nd.mm_ready = 0;
     nd.lt = nd.le = 0; nd.nbad[0] = nd.nbad[1] = 0; nd.chunk_base = 0; nd.nchunks = 0; nd.depth = 0;
 }
 
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_minmax(KdBuild<T> b) {
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
+    if (nd.mm_ready) return;               // installed with the node (see k_kd_count)
     const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
     T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
@@ -220,10 +227,42 @@ __global__ __launch_bounds__(kBlock) void k_kd_count(KdBuild<T> b) {
     if (chunk == 0 && threadIdx.x == 0) { nd.divfeat = f; nd.cutval = cut; }
     const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     unsigned lt = 0, le = 0;
-    for (int p = s + threadIdx.x; p < e; p += kBlock) { const T v = kd_coord(b.E, p, f); lt += v < cut; le += v <= cut; }
+    // The same read also gives the tight boxes of the two value classes {< cut} and {>= cut}: when no element equals the cut value
+    // (lt == le: every level of generic data) they ARE the two children (middleSplit_'s index is then lim1 = lim2 whatever count / 2
+    // is), so the children are created with their boxes and the next level's k_kd_minmax pass -- a sixth of a level -- has nothing to do.
+    T lo0[3], hi0[3], lo1[3], hi1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { lo0[j] = lo1[j] = Limits<T>::max_v; hi0[j] = hi1[j] = -Limits<T>::max_v; }
+    const T big = Limits<T>::max_v;
+    for (int p = s + threadIdx.x; p < e; p += kBlock) {
+        const Pt4<T> r = b.E[p];
+        const T v = kd_coord(b.E, p, f);
+        const bool a = v < cut;
+        lt += a; le += v <= cut;
+        const T xa = a ? r.x : big, ya = a ? r.y : big, za = a ? r.z : big, xb = a ? big : r.x, yb = a ? big : r.y, zb = a ? big : r.z;
+        lo0[0] = xa < lo0[0] ? xa : lo0[0]; lo0[1] = ya < lo0[1] ? ya : lo0[1]; lo0[2] = za < lo0[2] ? za : lo0[2];
+        lo1[0] = xb < lo1[0] ? xb : lo1[0]; lo1[1] = yb < lo1[1] ? yb : lo1[1]; lo1[2] = zb < lo1[2] ? zb : lo1[2];
+        const T xc = a ? r.x : -big, yc = a ? r.y : -big, zc = a ? r.z : -big, xd = a ? -big : r.x, yd = a ? -big : r.y, zd = a ? -big : r.z;
+        hi0[0] = xc > hi0[0] ? xc : hi0[0]; hi0[1] = yc > hi0[1] ? yc : hi0[1]; hi0[2] = zc > hi0[2] ? zc : hi0[2];
+        hi1[0] = xd > hi1[0] ? xd : hi1[0]; hi1[1] = yd > hi1[1] ? yd : hi1[1]; hi1[2] = zd > hi1[2] ? zd : hi1[2];
+    }
     unsigned tl, te;
     block_exclusive_scan(lt, &tl); block_exclusive_scan(le, &te);
-    if (threadIdx.x == 0) { if (tl) atomicAdd(&nd.lt, (int)tl); if (te) atomicAdd(&nd.le, (int)te); }
+    if (threadIdx.x == 0) { if (tl) atomicAdd(&nd.lt, (int)tl); if (te) atomicAdd(&nd.le, (int)te); b.chunk_bl[blockIdx.x] = (int)tl; }   // (chunk_bl: # < cut of this work item, see k_kd_lists)
+    __shared__ T s_mm[kBlock / 64][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const T a0 = wave_min(lo0[j]), c0 = wave_max(hi0[j]), a1 = wave_min(lo1[j]), c1 = wave_max(hi1[j]);
+        if (lane == 0) { s_mm[wave][j] = a0; s_mm[wave][3 + j] = c0; s_mm[wave][6 + j] = a1; s_mm[wave][9 + j] = c1; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x / 3, j = threadIdx.x % 3;
+        T a = s_mm[0][6 * k + j], c = s_mm[0][6 * k + 3 + j];
+        for (int w = 1; w < kBlock / 64; ++w) { const T x = s_mm[w][6 * k + j], y = s_mm[w][6 * k + 3 + j]; a = x < a ? x : a; c = y > c ? y : c; }
+        if (a <= c) { atomicMin(&nd.cmm_lo[k][j], enc(a)); atomicMax(&nd.cmm_hi[k][j], enc(c)); }      // (as k_kd_minmax folds a chunk; a class without elements here: a > c)
+    }
 }
 
 // Misplaced flags of planeSplit loop PH (0: "< cutval" about lim1 on [left,right); 1: "<= cutval" about lim2 on [lim1,right)).
@@ -240,6 +279,7 @@ __device__ __forceinline__ void kd_flags(const KdNode<T>& nd, int ph, int p, T v
 // the cut value (lt == le): its three launches then exit at once.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
+    if (ph == 1 && !*b.level_ph2) return;
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
@@ -262,12 +302,54 @@ __global__ __launch_bounds__(kBlock) void k_kd_bad_count(KdBuild<T> b, int ph) {
 // consecutive positions so ranks follow position order.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
+    if (ph == 1 && !*b.level_ph2) return;
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
     if (nd.active) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[ph] = 0; return; }
+    if (ph == 0 && chunk == 0 && threadIdx.x == 0 && nd.lt != nd.le) { *b.need_ph2 = 1; *b.level_ph2 = 1; }
     if (ph == 1 && nd.lt == nd.le) { if (chunk == 0 && threadIdx.x == 0) nd.nbad[1] = 0; return; }
     const int wi = blockIdx.x, wi0 = wi - chunk, nc = (nd.right - nd.left + kKdChunk - 1) / kKdChunk;
+    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
+    const int p0 = s + threadIdx.x * kKdItems;
+    if (ph == 0) {
+        // Loop 1 needs no count of the misplaced elements per work item (k_kd_bad_count): every ">= cut" element to the left of a
+        // misplaced-left one is itself left of lim1, hence misplaced too -- so the rank of a misplaced-left element is the number of
+        // ">= cut" elements before it, whatever lim1 is, and likewise the rank of a misplaced-right element is the number of "< cut"
+        // elements after it. Both come from the "< cut" counts per work item that the count pass left in chunk_bl.
+        unsigned before_ge = 0, after_lt = 0;
+        for (int c = threadIdx.x; c < nc; c += kBlock) {
+            const unsigned vlt = (unsigned)b.chunk_bl[wi0 + c];
+            const unsigned size_c = (unsigned)(min(nd.left + (c + 1) * kKdChunk, nd.right) - (nd.left + c * kKdChunk));
+            if (c < chunk) before_ge += size_c - vlt;
+            if (c > chunk) after_lt += vlt;
+        }
+        unsigned t_bg, t_al;
+        block_exclusive_scan(before_ge, &t_bg); block_exclusive_scan(after_lt, &t_al);
+        const int lim = nd.left + nd.lt;
+        const T cut = nd.cutval; const int f = nd.divfeat;
+        bool ge[kKdItems], ltf[kKdItems];
+        unsigned nge = 0, nlt = 0;
+#pragma unroll
+        for (int j = 0; j < kKdItems; ++j) {
+            const int p = p0 + j;
+            ge[j] = ltf[j] = false;
+            if (p < e) { const bool a = kd_coord(b.E, p, f) < cut; ltf[j] = a; ge[j] = !a; }
+            nge += ge[j]; nlt += ltf[j];
+        }
+        unsigned tg, tl2;
+        unsigned eg = block_exclusive_scan(nge, &tg);
+        unsigned el2 = block_exclusive_scan(nlt, &tl2);
+        const int base_l = nd.left + (int)t_bg, base_r = nd.left + (int)t_al;
+#pragma unroll
+        for (int j = 0; j < kKdItems; ++j) {
+            const int p = p0 + j;
+            if (p == lim) nd.nbad[0] = (int)(t_bg + eg);                           // # ">= cut" before lim1 = the number of pairs (lim1 < right always)
+            if (ge[j]) { if (p < lim) b.BLpos[base_l + eg] = p; ++eg; }
+            if (ltf[j]) { if (p >= lim) b.BRpos[base_r + (tl2 - 1 - el2)] = p; ++el2; }   // rank from the right end of the chunk
+        }
+        return;
+    }
     unsigned before_l = 0, after_r = 0, all_l = 0;
     for (int c = threadIdx.x; c < nc; c += kBlock) {
         const unsigned vl = (unsigned)b.chunk_bl[wi0 + c], vr = (unsigned)b.chunk_br[wi0 + c];
@@ -276,10 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
     unsigned t_bl, t_ar, t_all;
     block_exclusive_scan(before_l, &t_bl); block_exclusive_scan(after_r, &t_ar); block_exclusive_scan(all_l, &t_all);
     if (chunk == 0 && threadIdx.x == 0) nd.nbad[ph] = (int)t_all;
-    const int s = nd.left + chunk * kKdChunk, e = min(s + kKdChunk, nd.right);
     bool bl[kKdItems], br[kKdItems];
     unsigned nl = 0, nr = 0;
-    const int p0 = s + threadIdx.x * kKdItems;
 #pragma unroll
     for (int j = 0; j < kKdItems; ++j) {
         const int p = p0 + j;
@@ -303,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_lists(KdBuild<T> b, int ph) {
 // K5: swap the j-th misplaced-left with the j-th misplaced-right (std::swap in planeSplit, :1137 / :1155)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_kd_swap(KdBuild<T> b, int ph) {
+    if (ph == 1 && !*b.level_ph2) return;
     int id, chunk;
     if (!kd_locate(b, blockIdx.x, id, chunk)) return;
     KdNode<T>& nd = b.nodes[id];
@@ -339,6 +420,10 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
             for (int j = 0; j < 3; ++j) { l.bb_lo[j] = r.bb_lo[j] = nd.bb_lo[j]; l.bb_hi[j] = r.bb_hi[j] = nd.bb_hi[j]; }
             l.bb_hi[nd.divfeat] = nd.cutval;
             r.bb_lo[nd.divfeat] = nd.cutval;
+            if (lim1 == lim2) {                 // no element equals the cut value: the children are the two value classes (index == lim1), boxes known
+                for (int j = 0; j < 3; ++j) { l.mm_lo[j] = nd.cmm_lo[0][j]; l.mm_hi[j] = nd.cmm_hi[0][j]; r.mm_lo[j] = nd.cmm_lo[1][j]; r.mm_hi[j] = nd.cmm_hi[1][j]; }
+                l.mm_ready = r.mm_ready = 1;
+            }
             nd.child1 = c; nd.child2 = c + 1;
             l.depth = r.depth = nd.depth + 1;
             atomicMax(b.max_depth, nd.depth + 1);
@@ -366,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void k_kd_advance(KdBuild<T> b) {
         if (threadIdx.x == 0) s_items += (int)total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { b.next_cbase[n_next] = s_items; *b.n_items = s_items; *b.n_next = n_next; }
+    if (threadIdx.x == 0) { b.next_cbase[n_next] = s_items; *b.n_items = s_items; *b.n_next = n_next; *b.level_ph2 = 0; }
 }
 
 // ---- one workgroup per node, elements in place ----------------------------------------------------------------------------------------
@@ -489,15 +574,19 @@ __global__ __launch_bounds__(kFinThreads) void k_kd_finish(KdBuild<T> b) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { bb[j] = nd.bb_lo[j]; bb[3 + j] = nd.bb_hi[j]; }
             if (from_level) {
-                T lo[3], hi[3];
-                kd_fin_minmax(b.E, left, right, lo, hi);
-                fold_mm(lo, hi, 0);
+                const bool ready = nd.mm_ready != 0;          // (installed by k_kd_advance with the node)
+                if (!ready) {
+                    T lo[3], hi[3];
+                    kd_fin_minmax(b.E, left, right, lo, hi);
+                    fold_mm(lo, hi, 0);
+                }
                 if (tid == 0) s_i[4] = nd.active;
                 __syncthreads();
-                finish_mm(1);
+                if (!ready) finish_mm(1);
+                else if (tid < 6) s_mm[tid] = tid < 3 ? dec(nd.mm_lo[tid]) : dec(nd.mm_hi[tid - 3]);
                 in_roi2(bb, bb);
                 __syncthreads();
-                if (tid < 3 && s_mm[tid] <= s_mm[3 + tid]) { nd.mm_lo[tid] = enc(s_mm[tid]); nd.mm_hi[tid] = enc(s_mm[3 + tid]); }
+                if (!ready && tid < 3 && s_mm[tid] <= s_mm[3 + tid]) { nd.mm_lo[tid] = enc(s_mm[tid]); nd.mm_hi[tid] = enc(s_mm[3 + tid]); }
                 // a node handed over by complete (speculative) top levels is tested against the regions here
                 const bool stub = s_i[4] || (count > b.leaf_max && !s_in[0]);
                 if (stub) { if (tid == 0) nd.active = 1; break; }

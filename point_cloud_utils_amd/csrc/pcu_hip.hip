@@ -854,7 +854,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     b.n_nodes = counters; b.n_items = counters + 2;
     *err_out = counters + 3;
     b.n_sub = counters + 4; b.max_depth = counters + 5; b.n_real = counters + 6;
-    b.n_cur = counters + 7; b.n_next = counters + 8; b.need_ph2 = counters + 9;
+    b.n_cur = counters + 7; b.n_next = counters + 8; b.need_ph2 = counters + 9; b.level_ph2 = counters + 10;
     b.prof = nullptr;
     if (getenv("PCU_HIP_PROF_KD")) { if (ka.get(&b.prof, 16)) return -1; HIP_TRY(hipMemsetAsync(b.prof, 0, 16 * sizeof(long long), s)); }
     // planeSplit's second loop (elements EQUAL to the cut value) has no work on generic data, and its three launches per
@@ -890,7 +890,15 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     hipLaunchKernelGGL(k_kd_root<T>, dim3(1), dim3(64), 0, s, b, gp, M);
     if (speculative) HIP_TRY(hipEventRecord(sp.ev_init, s));          // the caller's buffers (points, grid parameters) are not read after this
     }
-    const int items_ub = (int)max_items;
+    // Level passes only while the nodes are large: below kd_finish_max() elements one workgroup per node finishes the rest
+    // (k_kd_finish). 0 = level passes all the way down to the LDS sub-trees (the round-3 flow).
+    const int fin_max = kd_finish_max();
+    int levels_sync = 0;
+    if (fin_max > 0) for (long long m = M; m > fin_max; m = (m + 1) >> 1) ++levels_sync;
+    // grid of a level pass: a level above levels_sync has at most 2^level nodes, i.e. M / chunk full work items + one partial per node;
+    // the general bound (max_items: every later level of the round-3 flow) is 5x that at 4M points, and blocks without a work item
+    // still wait for a slot beside the searches
+    const int items_ub = fin_max > 0 ? (int)std::min<size_t>(max_items, (size_t)M / kKdChunk + ((size_t)1 << std::min(levels_sync, 24)) + 2) : (int)max_items;
     // One level = 9 short launches; the count of nodes per level lives on the device and kernels of an exhausted
     // level exit at once, so levels need no host decision. Two consecutive levels (the ping-pong of the level
     // lists has period 2) are captured ONCE into a hipGraph and replayed: the expected log2(M / sub_max) + 2
@@ -900,7 +908,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
         hipLaunchKernelGGL(k_kd_minmax<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
         hipLaunchKernelGGL(k_kd_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb);
         for (int ph = 0; ph < (with_ph2 ? 2 : 1); ++ph) {
-            hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
+            if (ph == 1) hipLaunchKernelGGL(k_kd_bad_count<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);      // (loop 1 ranks from the count pass: k_kd_lists)
             hipLaunchKernelGGL(k_kd_lists<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
             hipLaunchKernelGGL(k_kd_swap<T>, dim3(items_ub), dim3(kBlock), 0, s, bb, ph);
         }
@@ -912,11 +920,6 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     auto enqueue_level_pair = [&](KdBuild<T> bb, bool with_ph2) { enqueue_one_level(bb, with_ph2); enqueue_one_level(bb, with_ph2); };
     int expected = 2;
     for (long long m = M; m > b.sub_max; m >>= 1) ++expected;
-    // Level passes only while the nodes are large: below kd_finish_max() elements one workgroup per node finishes the rest
-    // (k_kd_finish). 0 = level passes all the way down to the LDS sub-trees (the round-3 flow).
-    const int fin_max = kd_finish_max();
-    int levels_sync = 0;
-    if (fin_max > 0) for (long long m = M; m > fin_max; m = (m + 1) >> 1) ++levels_sync;
     const bool roi_mode = !speculative && roi_job && n_tied > 0 && n_tied <= kKdMaxRoi && getenv("PCU_HIP_KD_FULL") == nullptr;
     sub_launched = false;
     if (M > b.sub_max) {
