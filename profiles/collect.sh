@@ -9,7 +9,7 @@
 #   gpurun_out/<tag>_configs.jsonl              one bench.py --config line per config (parity checked inside the line)
 # then `python profiles/postprocess.py <tag>` (CPU side) turns them into the tracked summaries under profiles/.
 # Counter passes never carry trace domains other than --kernel-trace (gpurun refuses --pmc with sys/hip/hsa traces).
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -43,7 +43,7 @@ for c in ${PCU_COLLECT_LINES:-c1 c2 c3 c4 c5 gauss cluster outlier normals morto
   timeout 400 python $ROOT/bench.py --config $c --steps 10 --warmup 2 2>/dev/null | grep '^{' >> $OUT/${TAG}_configs.jsonl
 done
 for c in ${PCU_COLLECT_CONFIGS:-c1 c2 c3 c4 c5 gauss cluster outlier}; do
-  CB="python $ROOT/bench.py --config $c --steps 4 --warmup 2 --no-parity"
+  CB="python $ROOT/bench.py --config $c --steps 4 --warmup 2 --no-parity --no-kernel-events"
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${c}_trace -- $CB > $OUT/${TAG}_${c}_trace.log 2>&1
   summarise ${TAG}_${c}_trace
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_fetch -- $CB > $OUT/${TAG}_${c}_pmc_fetch.log 2>&1

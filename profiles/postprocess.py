@@ -4,7 +4,7 @@
    profiles/hbm_traffic.json (read by bench.py: measured HBM bytes per launch + issue-side fractions of the dominant kernel)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 N_SIMD, N_CU = 1024, 256          # MI355X: 256 CUs x 4 SIMD-32
 line = [l for l in open(os.path.join(G, f"{tag}_bench.json")) if l.startswith("{")][-1]
@@ -110,7 +110,7 @@ for c_ in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier"):
         continue
     txt_c = open(os.path.join(G, f"{tag}_{c_}_trace_summary.txt")).read().split("\n\n")[0].replace("/root/repo/", "")
     rows = [(r["name"], r["calls"], r["total_us"], r["avg_us"]) for r in json.load(open(kj))]
-    n_calls = 7                                                   # bench.py --config c --steps 4 --warmup 2: 1 initial + 2 warm-up + 4 timed calls
+    n_calls = 7                                                   # bench.py --config c --steps 4 --warmup 2 --no-parity --no-kernel-events: 1 initial + 2 warm-up + 4 timed calls
     def short(n): return n.replace("void pcu::", "").replace("pcu::", "").split("(")[0]
     fetch_c, write_c = pmc(f"{c_}_pmc", "fetch"), pmc(f"{c_}_pmc", "write")
     ks = {}
@@ -129,8 +129,8 @@ for c_ in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier"):
                 "hbm_bytes_per_call": sum((v["hbm_bytes_per_launch"] or 0) * v["launches_per_call"] for v in ks.values()),
                 "source": f"profiles/{tag}_{c_}_kernel_stats.txt, profiles/{tag}_{c_}_pmc.txt"}
     open(os.path.join(P, f"{tag}_{c_}_kernel_stats.txt"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {c_} --steps 4 --warmup 2 --no-parity ({n_calls} calls of the operator)\n" + txt_c.replace(ROOT + "/", "") + "\n")
-    lines_c = [f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --config {c_} --steps 4 --warmup 2 --no-parity`, mean per dispatch; KB, calibrated as in {tag}_pmc.txt",
+        f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {c_} --steps 4 --warmup 2 --no-parity --no-kernel-events ({n_calls} calls of the operator)\n" + txt_c.replace(ROOT + "/", "") + "\n")
+    lines_c = [f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --config {c_} --steps 4 --warmup 2 --no-parity --no-kernel-events`, mean per dispatch; KB, calibrated as in {tag}_pmc.txt",
                f"# per call of the operator: GPU time {cfgk[c_]['gpu_us_per_call']:.1f} us, HBM traffic {cfgk[c_]['hbm_bytes_per_call'] / 1e6:.1f} MB; dominant kernel: {dom_c}"]
     for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["total_us"]):
         f = mean(fetch_c.get(k, {}).get("FETCH_SIZE", [])); w = mean(write_c.get(k, {}).get("WRITE_SIZE", []))
