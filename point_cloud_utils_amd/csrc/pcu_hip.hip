@@ -1447,6 +1447,7 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
 }
 
+template <typename T> static int job_unlean(hipStream_t s, SearchJob<T>& j);
 template <typename T>
 static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* dataset, int64_t nr, int k, int max_leaf,
                        T* out_d, int64_t* out_i, unsigned flags, void* stream, pcu_hip_stats* st, const pcu_hip_index* pidx, int restarts) {
@@ -1505,6 +1506,12 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
             if ((rc = aalloc(ar, &job.out_i, (size_t)nq * k))) break;
         }
         job.leaf_max = max_leaf > 0 ? max_leaf : 10; job.tie_order = !(flags & PCU_HIP_NO_TIE_ORDER);
+        {   // k = 1 on a fresh pair of indexes: the lane kernel reads the coordinate and row-id streams only, so the Pt4 records are not
+            // written (grid2.h; 16 MB less per million points); whatever runs after the first read-back fills them in first (job_unlean)
+            static const bool no_lean = getenv("PCU_HIP_NO_LEAN") != nullptr;
+            const bool lean = !pidx && !no_lean && row_out && lane_k1_job(job) && job.ridx.bucketed && job.qidx.bucketed && job.ridx.one_pass && job.qidx.one_pass;
+            job.ridx.lean = job.qidx.lean = lean;
+        }
         tm.mark(0);
         if (pidx) { if ((rc = index_build<T>(job.qidx, dq, occ_q, s, /*defer_large=*/!c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c))) break; }
         else if ((rc = index_build_pair<T>(job.ridx, dr, occ, &job.qidx, dq, occ_q, s, !c->eager_large, rb, (int)(sizeof(ResultBlock) / 4), c))) break;
@@ -1519,6 +1526,12 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         tm.mark(2);
         HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
         if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
+        if (job.ridx.lean || job.qidx.lean) {
+            const int* hc0 = ((ResultBlock*)c->h_pinned)->counters[0];
+            bool clean = true;
+            for (int i = 0; i < C_N; ++i) clean = clean && hc0[i] == 0;
+            if (!clean && (rc = job_unlean(s, job))) break;      // stragglers, ties, give-ups: everything from here on may read Pt4 records
+        }
         if (lazy_wave) {
             const int* hc0 = ((ResultBlock*)c->h_pinned)->counters[0];
             if ((hc0[C_U1] > 0 || hc0[C_T1] > 0) && !hc0[C_SKEW] && !hc0[C_LARGE]) {       // stragglers beyond radius 2, possible ties, deferred lanes: the wave pass now
@@ -1785,6 +1798,18 @@ static int pair_unlean(hipStream_t s, PairState<T>& P) {
     hipLaunchKernelGGL(k_make_pt4<T>, dim3(nb0 + nb1), dim3(kBlock), 0, s, a, b, nb0);
     HIP_TRY(hipGetLastError());
     P.xy.qidx.lean = P.xy.ridx.lean = P.yx.qidx.lean = P.yx.ridx.lean = false;
+    return 0;
+}
+// The same for a single job (k_nearest_neighbors, k = 1).
+template <typename T>
+static int job_unlean(hipStream_t s, SearchJob<T>& j) {
+    GridIndex<T>& ix = j.qidx; GridIndex<T>& iy = j.ridx;
+    if (!ix.lean && !iy.lean) return 0;
+    const Pt4Side<T> a{ix.sorted, ix.n}, b{iy.sorted, iy.n};
+    const int nb0 = ix.lean ? std::min((ix.n + 8 + kBlock - 1) / kBlock, 2048) : 0, nb1 = iy.lean ? std::min((iy.n + 8 + kBlock - 1) / kBlock, 2048) : 0;
+    hipLaunchKernelGGL(k_make_pt4<T>, dim3(nb0 + nb1), dim3(kBlock), 0, s, a, b, nb0);
+    HIP_TRY(hipGetLastError());
+    ix.lean = iy.lean = false;
     return 0;
 }
 // A pass refused non-finite input (counter bit 4): the classification of both clouds (GridParams::nonfinite; [0] = x / source, [1] = y / target).
