@@ -101,7 +101,7 @@ def _map_chunks(kind, get_pair, mine, lanes, **kw):
     return rows
 
 
-def batched_hausdorff(get_pair, n_pairs, squared_distances=False, max_points_per_leaf=10, op=None, group=None, workers=3):
+def batched_hausdorff(get_pair, n_pairs, squared_distances=False, max_points_per_leaf=10, op=None, group=None, workers=4):
     """Two-sided Hausdorff distance of `n_pairs` independent pairs. `get_pair(p)` returns (x, y) for pair p and is only
     called for the pairs this rank owns. Returns an (n_pairs, 3) float64 array of (d, i, j) rows -- what
     hausdorff_distance(x, y, return_index=True) returns for each pair -- identical on all ranks.
@@ -120,7 +120,7 @@ def batched_hausdorff(get_pair, n_pairs, squared_distances=False, max_points_per
     return _gather_rows(rows, n_pairs, 3, group)
 
 
-def batched_chamfer(get_pair, n_pairs, p_norm=2, max_points_per_leaf=10, op=None, group=None, workers=3):
+def batched_chamfer(get_pair, n_pairs, p_norm=2, max_points_per_leaf=10, op=None, group=None, workers=4):
     """Chamfer distance of `n_pairs` independent pairs -> (n_pairs,) float64, identical on all ranks."""
     rank, world = _rank_world(group)
     mine = shard_pairs(n_pairs, rank, world)

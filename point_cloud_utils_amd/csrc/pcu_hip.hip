@@ -115,7 +115,7 @@ struct pcu_hip_ctx {
                                                                  // fill_parity -- left zeroed by its predecessor -- and zeroes the other one for its successor
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
-    std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 3;   // (measured on 262k-point pairs: 1 / 2 / 3 / 4 / 8 lanes = 106 / 66 / 54 / 64 / 67 us per pair: the host enqueue is the limit from 3 on)
+    std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;   // (262k-point pairs, round 4, us per pair at 1 / 2 / 3 / 4 / 5 / 6 / 8 lanes: 83 / 51 / 43 / 41 / 47 / 44 / 41 -- scratch/lanes.py; the host is the limit from 3 on)
     hipEvent_t batch_ev = nullptr;
 };
 
@@ -2562,7 +2562,7 @@ int pcu_hip_dot_##SUF(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, dou
 PCU_SINK(f32, float) PCU_SINK(f64, double)
 #undef PCU_SINK
 
-int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 3; return 0; }
+int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
 
 int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
 int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
