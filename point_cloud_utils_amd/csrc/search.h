@@ -824,7 +824,12 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
                 const int wl = eqm ? __ffsll((long long)eqm) - 1 : 0;        // a lane that holds the minimum
                 const bool many = __popcll(eqm) > 1;                          // ... met by two lanes: a possible tie
                 const unsigned rb = (unsigned)__shfl((int)wboff, wl, 64), rt = many ? (unsigned)__shfl((int)wboff, 63 - __clzll((long long)eqm), 64) : (unsigned)__shfl((int)wtoff, wl, 64);
-                const bool rtie = many || __shfl((int)wtie, wl, 64), rtie2 = (many && __popcll(eqm) > 2) || __shfl((int)wtie2, wl, 64) || (many && __shfl((int)wtie, wl, 64));
+                // (the flags of EVERY lane that holds the minimum count: with two such lanes, one of which met the minimum in two of its groups, there are
+                // three encounters -- consulting only the first lane's flags let the final "same record met twice" check clear a genuine tie: one query in
+                // 250k of a duplicated cloud, depending on the records' order inside their cell, found by the randomised sweep)
+                const bool holds = wbest == mn && wboff != 0xffffffffu;
+                const bool any_tie = __ballot(holds && wtie) != 0ull, any_tie2 = __ballot(holds && wtie2) != 0ull;
+                const bool rtie = many || any_tie, rtie2 = (many && __popcll(eqm) > 2) || any_tie2 || (many && any_tie);
                 if (lane_ == l) {
                     best = mn; lb = lb2; boff = eqm ? rb : 0xffffffffu; toff = rt; tie = rtie; tie2 = rtie2;
                     cx0 = bx0; cx1 = bx1; cy0 = by0; cy1 = by1; cz0 = bz0; cz1 = bz1;
