@@ -912,6 +912,13 @@ __device__ __forceinline__ bool lex_less(T d, int id, T d2, int id2) { return d 
 // (Measured and rejected, rounds 2 and 3: letting the block that finishes last also fold the fused call -- ticket, fuse_tail_body with
 // the block's 256 threads, hand-off to the host -- instead of the separate one-block k_fuse_tail launch: 21.4 us against 9.3 + 7.0 us.
 // The fold then runs strictly after the slowest block on a quarter of the threads; a launch boundary costs less.)
+// (scratch experiments: the wave pass without the subsample bound / without dropping candidates beyond the batch bound)
+#ifndef PCU_NO_SEED
+#define PCU_NO_SEED 0
+#endif
+#ifndef PCU_NO_BOUND_KILL
+#define PCU_NO_BOUND_KILL 0
+#endif
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, const SearchArgs<T> a1, int njobs, const int n_blocks) {
     const int lane = threadIdx.x & 63;
@@ -1065,7 +1072,9 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 const bool down = b_hi >= nbat || (b_lo >= 0 && !(bt & 1));
                 const int r0 = (down ? b_lo-- : b_hi++) * step;
                 const int r = r0 + (sp == 2 ? lane >> 1 : lane);
-                const T bound = is_ball && !(bw < ball) ? ball : bw;
+                // (the bound with the near-tie margin of the extraction below: what is pruned or dropped lies beyond every near tie of the k-th best)
+                const T bound0 = is_ball && !(bw < ball) ? ball : bw;
+                const T bound = bound0 < Limits<T>::max_v ? bound0 * ((T)1 + (T)8 * Limits<T>::eps) : bound0;
                 unsigned s = 0, e = 0;
                 if (r < nrows) {
                     const int cz = z0 + r / ny, cy = y0 + r % ny;
@@ -1106,7 +1115,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                         const Pt4<T>& c = cc[u];
                         const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
                         const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
-                        take(kill_if(d, (u > 0 && p + (unsigned)u >= le) || d > bound), (int)c.idx);      // (beyond the bound: never among the k best, see above)
+                        take(kill_if(d, (u > 0 && p + (unsigned)u >= le) || (!PCU_NO_BOUND_KILL && d > bound)), (int)c.idx);      // (beyond the bound: never among the k best, see above)
                     }
                 }
                 // heavy rows (a dense cluster next to the query): all 64 lanes stride over the row together, coalesced; every
@@ -1131,7 +1140,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                             const Pt4<T>& c = hc[u];
                             const T dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
                             const T d = ((dx * dx) + (dy * dy)) + (dz * dz);
-                            take(kill_if(d, (u > 0 && p + 64u * (unsigned)u >= he) || d > bound), (int)c.idx);
+                            take(kill_if(d, (u > 0 && p + 64u * (unsigned)u >= he) || (!PCU_NO_BOUND_KILL && d > bound)), (int)c.idx);
                         }
                     }
                 }
@@ -1160,7 +1169,14 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                     bd[K - 1] = Limits<T>::max_v; bi[K - 1] = 0x7fffffff;
                 }
                 if (lane == (j & 63)) { if (j < 64) { my_d = md; my_i = mi; } else { my_d2 = md; my_i2 = mi; } }
-                if (j <= kreq && mi != 0x7fffffff && md == prev_d) tie = true;
+                // "Tied" here includes NEAR ties, within a few ulps of the distance: nanoflann prunes a branch by `mindistsq`, a sum it updates
+                // incrementally in the input type (nanoflann.hpp:1601-1613), and when the terms are huge against the spacing of the candidates -- a
+                // float32 query cloud at offset 1000 from a unit-size dataset: d2 ~ 3e6, ulp 0.25 -- its rounding discards the branch of the true
+                // minimum: the reference then returns a neighbour one ulp WORSE than the minimum of its own distance arithmetic (141 of 2652
+                // queries in the randomised sweep's seed 405 case 289). Such a query is not ours to answer by a minimum: it goes to the
+                // reference's own traversal (kd_order.h) with the genuinely tied ones. Near ties between well-conditioned distances are as rare
+                // as exact ones.
+                if (j <= kreq && mi != 0x7fffffff && prev_d >= (T)0 && md - prev_d <= prev_d * ((T)8 * Limits<T>::eps)) tie = true;
                 if (j == kreq - 1) kth = md;
                 prev_d = md;
             }
@@ -1169,11 +1185,13 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
                 if (kth < Limits<T>::max_v) ball = kth; else R = min(4 * R, 4096);
                 continue;
             }
-            certified = is_ball || kth < face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
+            T kw = kth * ((T)1 + (T)8 * Limits<T>::eps);            // (the near-tie margin; none where it would overflow)
+            if (!(kw <= Limits<T>::max_v)) kw = kth;
+            certified = is_ball || kw < face_lower_bound(g, q.x, q.y, q.z, x0, x1, y0, y1, z0, z1);
             if (certified || !esc) break;
             if (kth < Limits<T>::max_v) ball = kth;                // k points seen: the ball round finishes the query
             else if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == Gx - 1 && y1 == Gy - 1 && z1 == Gz - 1) break;      // (cannot happen on an open grid: its whole box certifies)
-            else if (!seeded) { seed_next = true; seeded = true; }  // fewer than k points in the box: a bound from the subsample first
+            else if (!seeded && !PCU_NO_SEED) { seed_next = true; seeded = true; }  // fewer than k points in the box: a bound from the subsample first
             else R = min(4 * R, 4096);                             // ... then a wider box (whole grid: certified)
         }
         if (certified && a.fuse != FUSE_NONE) {

@@ -20,6 +20,10 @@ dq, dr = rng.choice(dists), rng.choice(dists)
 q, r = make(rng, n, dq, dtype), make(rng, m, dr, dtype)
 print(f"case {case}: {dtype.__name__} n={n} m={m} k={k} q={dq} r={dr}", flush=True)
 kind = "ref"
+if os.environ.get("ONLY_KNN"):
+    d, c = pcu.k_nearest_neighbors(q, r, k); d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind="ref")
+    bad = np.nonzero((c != c0) | (d.view(np.uint32) != np.asarray(d0).view(np.uint32)))[0]
+    print("knn bad rows", bad.size, pcu.last_stats()["n_tie_true"], pcu.last_stats()["n_passes"], flush=True); sys.exit(0)
 if os.environ.get("ONLY_CH"):
     ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True); ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind="ref")
     print("chamfer idx mismatches", (cxy != cxy0).sum(), (cyx != cyx0).sum(), np.nonzero(cyx != cyx0)[0][:5], flush=True)

@@ -65,6 +65,34 @@ def nonfinite_cases():
 P_NORMS = (2, 1, np.inf, -np.inf, 0, 3)
 
 
+def near_tie_cases():
+    """near_tie_*.npz: float32 clouds at offset 1000 from each other (the randomised sweep's seed 405, cases 289 and 37, regenerated draw by
+    draw). d2 ~ 3e6 with an ulp of 0.25: the reference's incremental branch bound (nanoflann.hpp:1601-1613) discards the branch of the true
+    minimum for some queries, i.e. its answer is one ulp WORSE than the minimum of its own distance arithmetic (asserted here). k = 1, squared."""
+    def make(rng, n, dist):
+        if dist == "clusters":
+            c = rng.random((8, 3)); a = c[rng.integers(0, 8, n)] + rng.normal(0, 0.003, (n, 3))
+        elif dist == "offset": a = rng.random((n, 3)) * 1e-3 + 1000.0
+        elif dist == "sphere": v = rng.normal(size=(n, 3)); a = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+        return np.ascontiguousarray(a.astype(np.float32))
+    dists = ["uniform", "plane", "line", "clusters", "dups", "lattice", "offset", "aniso", "sphere", "mixed"]
+    worse = 0
+    for tag, case in (("a", 289), ("b", 37)):
+        rng = np.random.default_rng(405 * 1000 + case)
+        assert rng.random() < 0.6; rng.random()                      # (float32; size class)
+        n = int(rng.integers(1, 3000)); m = int(rng.integers(1, 3000))
+        rng.choice([1, 1, 1, 2, 5, 16])
+        dq, dr = rng.choice(dists), rng.choice(dists)
+        q, r = make(rng, n, dq), make(rng, m, dr)
+        for name, a, b in ((f"near_tie_{tag}_xy", q, r), (f"near_tie_{tag}_yx", r, q)):
+            d, c = oracle.knn(a, b, 1, squared_distances=True, kind="ref")
+            D = (a[:, None, :] - b[None, :, :]).astype(np.float32)
+            worse += int((np.asarray(d).reshape(-1) > ((D[..., 0] * D[..., 0] + D[..., 1] * D[..., 1]) + D[..., 2] * D[..., 2]).min(axis=1)).sum())
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), q=a, r=b, k=np.int64(1), squared=np.int64(1), d=d, c=c)
+    assert worse > 0, "the fixtures no longer hold a query whose reference answer is not the minimum"
+    print("wrote 4 near-tie fixtures;", worse, "reference answers are not the minimum of their own arithmetic")
+
+
 def nonfinite_metric_cases(rng):
     """nf_{f32,f64}_metrics.npz: the metrics on clouds with non-finite rows, where the reference has a stable answer
     (src/point_cloud_distance.cpp:90-93,223 and __init__.py:112-115: unmatched source rows carry -1 / -1.0, Hausdorff's max ignores
@@ -108,7 +136,10 @@ def main():
     assert oracle.have_ref(), "needs /root/reference (oracle/_ref)"
     if "--only-nonfinite" in sys.argv:
         return nonfinite_cases()
+    if "--only-near-ties" in sys.argv:
+        return near_tie_cases()
     nonfinite_cases()
+    near_tie_cases()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import read_ply_vertices
     rng = np.random.default_rng(20250321)
