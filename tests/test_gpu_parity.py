@@ -298,7 +298,6 @@ def test_rescued_queries_keep_their_ties(pcu, oracle_kind):
     assert pcu.hausdorff_distance(y, x, return_index=True) == oracle.hausdorff_distance(y, x, return_index=True, kind=oracle_kind)
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_far_float32_queries_follow_the_reference_through_near_ties(pcu, oracle_kind):
     """float32 clouds at offset 1000 from each other (goldens near_tie_*: the randomised sweep's seed 405, cases 289 and 37): d2 ~ 3e6 with
     an ulp of 0.25, and the reference's incremental branch bound (nanoflann.hpp:1601-1613) discards the branch of the true minimum for
