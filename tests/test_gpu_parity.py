@@ -316,6 +316,10 @@ def test_far_float32_queries_follow_the_reference_through_near_ties(pcu, oracle_
             assert abs(float(ch) - float(ch0)) <= 1e-4 * float(ch0)
             assert pcu.hausdorff_distance(a, b, return_index=True) == oracle.hausdorff_distance(a, b, return_index=True, kind=oracle_kind)
             assert pcu.one_sided_hausdorff_distance(a, b) == oracle.one_sided_hausdorff_distance(a, b, kind=oracle_kind)
+            # the fused calls (no rows): the value of the arg-max query is the reference's, not the minimum's, when that query is near-tied
+            assert pcu.hausdorff_distance(a, b) == oracle.hausdorff_distance(a, b, kind=oracle_kind)
+            assert pcu.hausdorff_distance(a, b, squared_distances=True) == oracle.hausdorff_distance(a, b, squared_distances=True, kind=oracle_kind)
+            assert abs(float(pcu.chamfer_distance(a, b)) - float(ch0)) <= 1e-4 * float(ch0)
     assert worse > 0          # (the case is there: for some of these queries the reference's answer is not the minimum)
 
 
