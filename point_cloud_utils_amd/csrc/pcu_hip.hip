@@ -589,7 +589,7 @@ template <typename T>
 static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
     // (fused calls: the fixed grid always -- the arg-max slots are one per wave of that grid)
-    const int blocks = (a.qcount_dev || a.fuse != FUSE_NONE) ? kWaveBlocks : std::max(1, std::min((a.nq + 3) / 4, 16384));
+    const int blocks = (a.qcount_dev || a.fuse != FUSE_NONE) ? kWaveBlocks : std::max(1, std::min((a.nq + (a1 && !a1->qcount_dev ? a1->nq : 0) + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, blocks); break;
     switch (K) {
@@ -766,6 +766,33 @@ template <typename T>
 static int search_enqueue_pair(pcu_hip_ctx* c, hipStream_t s, const SearchJob<T>& j0, const SearchJob<T>& j1, pcu_hip_stats* st, int what = 3) {
     if (!(lane_k1_job(j0) && lane_k1_job(j1))) {
         if (j0.fuse || j1.fuse) return fail(PCU_HIP_ERR_RUNTIME, "internal: fused epilogue without the paired k = 1 pass");
+        // Two small clouds (wave-per-query from the start, see search_enqueue): both directions share each of the two launches -- such a
+        // call is a chain of launch latencies (config 1, 10k-vs-10k: 4 wave launches of 46 + 9 + 43 + 10 us were 60 % of its GPU time).
+        auto wave_only = [](const SearchJob<T>& j) { return (j.k > kMaxKLane || j.qidx.n < kWaveOnlyBelow) && j.n_fine == 0; };
+        static const bool no_merge = getenv("PCU_HIP_NO_WAVE_MERGE") != nullptr;
+        if (!no_merge && what == 3 && wave_only(j0) && wave_only(j1) && j0.k == j1.k) {
+            const int KL = std::max(2, pow2_at_least(j0.k + 1));
+            SearchArgs<T> b[2];
+            for (int d = 0; d < 2; ++d) {
+                const SearchJob<T>& j = d ? j1 : j0;
+                b[d] = base_args(j, j.ridx);
+                b[d].ties = j.sc.tt; b[d].n_ties = j.sc.counters + C_TT;
+                b[d].qlist = nullptr; b[d].qcount_dev = nullptr; b[d].nq = j.qidx.n; b[d].R = 1;      // every query, radius 1, total order
+                b[d].unresolved = j.sc.u1; b[d].n_unresolved = j.sc.counters + C_U1;
+                if (j.skew_check) { b[d].skew_limit = (float)(j.skew_hi * (j.occ + 1.0) * (double)j.ridx.n); b[d].skew_far = (float)(kSkewFactor * (j.occ + 1.0) * (double)j.ridx.n); b[d].skew_lo = (float)(j.skew_lo * (j.occ + 1.0) * (double)j.ridx.n); }
+            }
+            if (launch_search_wave<T>(KL, b[0], s, &b[1])) return -1;
+            for (int d = 0; d < 2; ++d) {
+                const SearchJob<T>& j = d ? j1 : j0;
+                b[d].nq = 0; b[d].skew_limit = 0.f; b[d].skew_lo = 0.f;
+                b[d].qlist = j.sc.u1; b[d].qcount_dev = j.sc.counters + C_U1; b[d].R = 2;             // stragglers, radius 2
+                b[d].unresolved = j.sc.u2; b[d].n_unresolved = j.sc.counters + C_U2;
+                b[d].escalate = wave_escalates();
+            }
+            if (launch_search_wave<T>(KL, b[0], s, &b[1])) return -1;
+            if (st) st->n_passes += 4;
+            return 0;
+        }
         if (search_enqueue(c, s, j0, st, /*zero_counters=*/false)) return -1;
         return search_enqueue(c, s, j1, st, false);
     }

@@ -159,7 +159,7 @@ SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINU
             # fused calls, level passes all the way down / one workgroup for the whole tie-order tree, refits one direction at a time
             "PCU_HIP_BUILD_V1=1", "PCU_HIP_NO_LEAN=1", "PCU_HIP_ROW_OUT_MIN_K=4", "PCU_HIP_FUSED_WAVE=1", "PCU_HIP_KD_FINISH_MAX=0",
             "PCU_HIP_KD_FINISH_MAX=1000000000", "PCU_HIP_NO_SKEW_OVERLAP=1", "PCU_HIP_SPEC_PRIORITY=1", "PCU_HIP_PROF_BUILD2=1",
-            "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255"]
+            "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255", "PCU_HIP_NO_WAVE_MERGE=1"]
 
 
 @pytest.mark.gpu
