@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--pairs", type=int, default=32, help="c4: pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline line at N = 1: do not run BASELINE configs c1-c5 behind the timed region (the `configs` object)")
     ap.add_argument("--no-kernel-events", action="store_true", help="--config lines: skip the extra steps that time the dominant kernel with HIP events (profiler runs count the operator's calls)")
     return ap.parse_args()
 
@@ -222,7 +223,10 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         cnt = counters()
         traffic = cnt.get("k_search1_flat_f32_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": "k_search1_flat<float> (both directions in one launch, fused Chamfer epilogue)",
+        roof = {"bound": "hbm", "actual_bound": "valu_issue",
+                "bound_note": "`bound` is the roofline BASELINE.json designates (achieved = SURVEY 8d algorithmic bytes / launch time against the HBM peak); what the "
+                              "kernel actually runs into is vector-instruction issue (counters below), as SURVEY 8d's consistency note predicts for an exact pruned 3-D KNN",
+                "kernel": "k_search1_flat<float> (both directions in one launch, fused Chamfer epilogue)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                 "alg_bytes_per_launch": alg_bytes, "alg_bytes_rule": "SURVEY 8d Chamfer row: 24 B per query-point",
@@ -238,6 +242,10 @@ def main():
                   "vmem_insts_per_wave", "valu_issue_frac_at_2_cycles", "counters_source"):
             if k in cnt:
                 roof[k] = cnt[k]
+        # `traffic` and the counter fields are NOT measured by this run: they are the rocprofv3 --pmc collection tracked in profiles/hbm_traffic.json,
+        # stamped with the commit it was collected at (profiles/collect.sh); the timing fields above are live
+        roof["counters_commit"] = cnt.get("commit")
+        roof["counters_note"] = "traffic + issue counters: tracked rocprofv3 --pmc collection (profiles/hbm_traffic.json) taken at `counters_commit`; everything else in this object is measured by this run"
         out = {
             "metric": "query-points/s, Chamfer 1M-vs-1M fp32", "value": value, "unit": "query-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
@@ -272,6 +280,19 @@ def main():
                              "checker": "oracle/_ref (the reference's nanoflann.hpp)" if oracle.have_ref() else "oracle port"}
             assert rel <= 1e-4, f"Chamfer value differs from the reference: {results[0]} vs {ch0}"
             assert idx_equal, "Chamfer correspondences differ from the reference"
+        # Every BASELINE config in front of the driver (N = 1 only; OUTSIDE the timed region above): c1-c5 through the same code as
+        # `--config cN`, a few steps each, parity against the reference and its CPU time inside each entry.
+        if world == 1 and not args.no_configs:
+            del x, y
+            out["configs"] = {}
+            for cfg, steps_c, warm_c in (("c1", 50, 5), ("c2", 30, 3), ("c3", 8, 2), ("c4", 8, 2), ("c5", 30, 3)):
+                sub = argparse.Namespace(**vars(args))
+                sub.config, sub.steps, sub.warmup = cfg, steps_c, warm_c
+                t_c = time.perf_counter()
+                line = other_config(sub, pcu, np, torch, dist, dev, rank, world, distributed, sync_all, emit=False)
+                line["wall_s"] = round(time.perf_counter() - t_c, 1)
+                out["configs"][cfg] = line
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
@@ -291,8 +312,8 @@ def config_roofline(cfg, alg, step_s, k_ms, k_calls):
     live_ms = k_ms / k_calls if k_calls else None
     prof_ms = ck["dominant_avg_us"] * ck.get("dominant_launches_per_call", 1.0) / 1e3 if ck.get("dominant_avg_us") else None
     achieved = alg / step_s / 1e9
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": ck.get("hbm_bytes_per_call"), "alg_bytes_per_call": alg,
+    roof = {"bound": "hbm", "actual_bound": ck.get("actual_bound", "valu_issue"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": ck.get("hbm_bytes_per_call"), "counters_commit": ck.get("commit"), "alg_bytes_per_call": alg,
             "note": "whole operator call (all launches + host) against SURVEY 8d's algorithmic bytes; traffic = measured HBM bytes of the whole call "
                     "(rocprofv3 --pmc, profiles/config_kernels.json: a tracked collection, see `source`)",
             "source": ck.get("source"), "gpu_us_per_call_rocprof": ck.get("gpu_us_per_call")}
@@ -308,9 +329,10 @@ def config_roofline(cfg, alg, step_s, k_ms, k_calls):
     return roof
 
 
-def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync_all):
-    """BASELINE configs 2-5: same timing protocol (device-resident inputs, barrier + sync, max over ranks), parity against
-    the oracle outside the timed region. One JSON line on rank 0."""
+def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync_all, emit=True):
+    """BASELINE configs 1-5 (and the uneven-cloud / next-row workloads): same timing protocol (device-resident inputs, barrier + sync, max over
+    ranks), parity against the oracle outside the timed region. One JSON line on rank 0 -- or, with emit=False (the headline run attaches
+    every BASELINE config to its own line), the line's dict is returned instead (rank 0; no process-group teardown)."""
     import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import cloud
@@ -519,7 +541,11 @@ def other_config(args, pcu, np, torch, dist, dev, rank, world, distributed, sync
                "parity": parity}
         if "obj" in cpu and world == 1:
             out["cpu_baseline"] = cpu["obj"]
+        if not emit:
+            return out
         print(json.dumps(out), flush=True)
+    if not emit:
+        return None
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

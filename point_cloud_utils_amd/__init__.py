@@ -31,12 +31,19 @@ __all__ = ["k_nearest_neighbors", "one_sided_hausdorff_distance", "hausdorff_dis
            "morton_encode", "morton_decode", "morton_add", "morton_subtract", "morton_knn",
            "downsample_point_cloud_on_voxel_grid", "deduplicate_point_cloud",
            "pairwise_distances", "sinkhorn", "earth_movers_distance",
-           "last_stats", "set_timing", "set_cell_occupancy", "device_count", "DatasetIndex"]
+           "last_stats", "set_timing", "set_cell_occupancy", "device_count", "DatasetIndex", "cancel"]
 
 _last_stats = [None]      # the Stats struct of the most recent call (turned into a dict on demand)
 # PCU_HIP_NO_TIE_ORDER=1: skip the kd-tree tie-order resolver (exact ties then ordered by (d2, row)); for experiments.
 _ENV_FLAGS = _lib.NO_TIE_ORDER if __import__("os").environ.get("PCU_HIP_NO_TIE_ORDER", "0") not in ("", "0") else 0
 _TIMING = [int(__import__("os").environ.get("PCU_HIP_TIMING", "0") or 0)]
+
+
+def cancel():
+    """Ask the call that is in flight (any thread of this process) to stop: it returns early and raises KeyboardInterrupt in its caller, as
+    Ctrl-C does -- the reference polls PyErr_CheckSignals() inside its search loops (src/point_cloud_distance.cpp:60-75, 96-98). Callable from
+    another thread or a signal handler; a request made while no call is running is dropped when the next one starts."""
+    _lib.lib().pcu_hip_cancel()
 
 
 def set_timing(level):

@@ -15,6 +15,7 @@ TIME_KERNELS = 16
 STREAM_GIVEN = 32
 
 ERR_INVALID = -1
+ERR_CANCELLED = -4
 
 
 class Stats(ctypes.Structure):
@@ -102,6 +103,13 @@ def lib():
         L.pcu_hip_index_size.argtypes = [vp]
         L.pcu_hip_index_destroy.argtypes = [vp]
         L.pcu_hip_index_destroy.restype = None
+        L.pcu_hip_cancel.restype = None
+        L.pcu_hip_watch_sigint.argtypes = [ci]
+        # Ctrl-C during a long call (the reference: PyErr_CheckSignals per query -> KeyboardInterrupt, src/point_cloud_distance.cpp:60-75,96-98): the
+        # library chains a SIGINT handler in front of Python's, so a call in flight returns early and the interpreter raises KeyboardInterrupt.
+        # PCU_HIP_NO_SIGINT=1 leaves the process's signal handlers alone (then a call runs to its end before the interrupt is seen).
+        if os.environ.get("PCU_HIP_NO_SIGINT", "0") in ("", "0"):
+            L.pcu_hip_watch_sigint(1)
         _lib = L
     return _lib
 
@@ -180,4 +188,6 @@ def check(rc):
     msg = last_error()
     if rc == ERR_INVALID:
         raise ValueError(msg)
+    if rc == ERR_CANCELLED:         # (after SIGINT the interpreter raises its own KeyboardInterrupt before this line; this is pcu_hip_cancel() from a thread)
+        raise KeyboardInterrupt(msg)
     raise RuntimeError(f"libpcu_hip: {msg}")

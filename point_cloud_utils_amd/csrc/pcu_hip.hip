@@ -17,6 +17,8 @@
 #include <vector>
 #include <chrono>
 #include <atomic>
+#include <signal.h>
+#include <time.h>
 
 #include "../../include/pcu_hip.h"
 #include "grid.h"
@@ -48,6 +50,47 @@ static int fail(int code, const char* fmt, ...) {
     do { hipError_t e_ = (x); if (e_ != hipSuccess)                                             \
         return fail(PCU_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// ------------------------------------------------------------------------------------------------ cancellation
+// The reference polls PyErr_CheckSignals() per query and per kd-tree node and turns Ctrl-C into KeyboardInterrupt
+// (src/point_cloud_distance.cpp:60-75, 96-98; external/nanoflann/nanoflann.hpp:1004). Here a call is a sequence of host phases (enqueue, wait,
+// decide, enqueue ...), and every host wait is a bounded poll that also looks at one process-wide flag:
+//   pcu_hip_cancel()            sets it (any thread, async-signal-safe);
+//   pcu_hip_watch_sigint(1)     chains a SIGINT handler in front of the installed one (Python's): it sets the flag and then calls the previous
+//                               handler, so the interpreter still records its KeyboardInterrupt -- which it raises as soon as the C call returns.
+// A call that sees the flag stops enqueuing, drains the device (kernels cannot be killed; what is queued is one phase: milliseconds), and
+// returns PCU_HIP_ERR_CANCELLED. Every entry point clears the flag on entry (DeviceGuard). Contexts reset their cross-call device state
+// (the "no memset" fill words, the speculative tree top) when they see that a call was abandoned since their last one (g_cancel_epoch).
+static std::atomic<int> g_cancel{0};
+static std::atomic<unsigned> g_cancel_epoch{0};
+static struct sigaction g_prev_sigint;
+static std::atomic<int> g_sigint_watched{0};
+static void pcu_on_sigint(int sig, siginfo_t* info, void* uc) {
+    g_cancel.store(1, std::memory_order_relaxed);
+    if (g_prev_sigint.sa_flags & SA_SIGINFO) { if (g_prev_sigint.sa_sigaction) g_prev_sigint.sa_sigaction(sig, info, uc); }
+    else if (g_prev_sigint.sa_handler != SIG_DFL && g_prev_sigint.sa_handler != SIG_IGN && g_prev_sigint.sa_handler) g_prev_sigint.sa_handler(sig);
+    else if (g_prev_sigint.sa_handler == SIG_DFL) { signal(SIGINT, SIG_DFL); raise(SIGINT); }        // no handler before ours: the default action
+}
+static int cancelled() {
+    (void)hipDeviceSynchronize();                  // nothing of the abandoned call may still be running when its buffers are reused or freed
+    g_cancel_epoch.fetch_add(1, std::memory_order_relaxed);
+    return fail(PCU_HIP_ERR_CANCELLED, "cancelled (pcu_hip_cancel / SIGINT) while waiting for the GPU");
+}
+static inline bool cancel_requested() { return g_cancel.load(std::memory_order_relaxed) != 0; }
+// hipStreamSynchronize as a bounded poll: tight for the first 2 ms (short calls keep their latency), then 50 us naps.
+static int wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool nap = false;
+    for (unsigned it = 0;; ++it) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(PCU_HIP_ERR_RUNTIME, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        if (cancel_requested()) return cancelled();
+        if (!nap && (it & 0x3f) == 0x3f && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) nap = true;
+        if (nap) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
+    }
+}
+#define HIP_WAIT(s) do { const int w_ = wait_stream(s); if (w_) return w_; } while (0)
+
 // Host-side profile of a call (PCU_HIP_HOST_PROF=1; diagnostics): wall-clock marks at entry, first launch, last launch, result seen, exit;
 // the mean spans of every 1000 calls go to stderr. Tells the Python wrapper's share of a step from the library's (scratch/hostgap.py).
 struct HostProf {
@@ -69,6 +112,13 @@ struct HostProf {
 };
 static HostProf g_hprof;
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds for the CURRENT device only: a process with contexts on several GPUs has to opt every
+// kernel in on each of them. One bit per device and call site; true = this (site, device) has not been set yet.
+static bool attr_unset_here(std::atomic<unsigned long long>& mask) {
+    int d = 0; (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    return !(mask.fetch_or(bit) & bit);
+}
 // ------------------------------------------------------------------------------------------------ context
 struct pcu_hip_ctx {
     int device = 0;
@@ -115,6 +165,7 @@ struct pcu_hip_ctx {
                                                                  // fill_parity -- left zeroed by its predecessor -- and zeroes the other one for its successor
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
+    unsigned cancel_epoch = 0;                // g_cancel_epoch at this context's last call (ctx_begin: reset of the cross-call device state after an abandoned call)
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;   // (262k-point pairs, round 4, us per pair at 1 / 2 / 3 / 4 / 5 / 6 / 8 lanes: 83 / 51 / 43 / 41 / 47 / 44 / 41 -- scratch/lanes.py; the host is the limit from 3 on)
     hipEvent_t batch_ev = nullptr;
 };
@@ -127,6 +178,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct DeviceGuard {
     int prev = -1, dev = -1;
     explicit DeviceGuard(int device) : dev(device) {
+        g_cancel.store(0, std::memory_order_relaxed);     // (every entry point constructs one guard first: a cancellation request is for the call in flight)
         if (dev < 0) return;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) (void)hipSetDevice(dev);
@@ -182,6 +234,16 @@ static int kd_ws_reserve(pcu_hip_ctx* c, size_t bytes) {
 static void ctx_end(pcu_hip_ctx* c);
 static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
     ctx_end(c);                                 // drop overflow blocks left by a call that failed midway
+    // A call of this process was abandoned (cancelled()) since this context's last one: whatever device state one call leaves for the next
+    // may be half-made -- the "no memset" fill words of the one-pass build (grid2.h), a speculative tree top in flight.
+    const unsigned ep = g_cancel_epoch.load(std::memory_order_relaxed);
+    if (ep != c->cancel_epoch) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->fill2) HIP_TRY(hipMemset(c->fill2, 0, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
+        c->fill_parity = 0;
+        c->kd_spec.active = c->kd_spec.pending = false;
+        c->cancel_epoch = ep;
+    }
     want_bytes += c->extra_hint;                // what earlier calls had to hipMalloc on top of their estimate (refitted / coarse grids)
     if (want_bytes > c->arena_cap) {
         if (c->arena) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->arena)); c->arena = nullptr; c->arena_cap = 0; }
@@ -342,7 +404,6 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         kBkThreads * StagedPts<T>::n >= run_floor) {
         unsigned long long* const fw = ctx->fill2 + (size_t)ctx->fill_parity * kFillWords;
         unsigned long long* const fw_next = ctx->fill2 + (size_t)(ctx->fill_parity ^ 1) * kFillWords;
-        ctx->fill_parity ^= 1;
         const int bpts = kBkThreads * StagedPts<T>::n;
         auto side = [&](const GridIndex<T>& g, const T* p, double occ, int k) {
             return Build2Side<T>{p, g.n, g.gp, g.shift, occ, g.max_cells, g.h_want, fw + (size_t)k * kStagedMaxBuckets, fw + 2 * kStagedMaxBuckets + k,
@@ -355,16 +416,15 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         static long long* prof2 = nullptr;
         if (do_prof2) { if (!prof2) HIP_TRY(hipMalloc((void**)&prof2, 16 * sizeof(long long))); HIP_TRY(hipMemsetAsync(prof2, 0, 16 * sizeof(long long), s)); }
         s0.prof = s1.prof = do_prof2 ? prof2 : nullptr;
-        static bool attr_set2[2] = {false, false};
-        if (!attr_set2[sizeof(T) == 4 ? 0 : 1]) {
+        static std::atomic<unsigned long long> attr_set2[2];
+        if (attr_unset_here(attr_set2[sizeof(T) == 4 ? 0 : 1])) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>()));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
-            attr_set2[sizeof(T) == 4 ? 0 : 1] = true;
         }
         hipLaunchKernelGGL(k_bucket_onepass3<T>, dim3(c0 + c1), dim3(kBkThreads), onepass3_lds_bytes<T>(), s, s0, s1, c0);
         if (do_prof2) {
-            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
             const double nb = h[15] > 0 ? (double)h[15] * 100.0 : 100.0;
             fprintf(stderr, "[onepass3 prof] blocks %lld | mean us per block: layout %.2f  points in %.2f  keys+ranks %.2f  scan+reservations %.2f  staging %.2f  run copies %.2f  drain %.2f\n",
                     h[15], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb);
@@ -374,8 +434,9 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         if (do_prof2) { HIP_TRY(hipMemsetAsync(prof2, 0, 16 * sizeof(long long), s)); }
         Build2Args<T> sa; sa.a[0] = s0; sa.a[1] = s1;
         hipLaunchKernelGGL(k_bucket_sort2<T>, dim3(t0 + t1 + (b ? 2 : 1)), dim3(kSortThreads), bucket_sort_lds_bytes<T>(cnt_cap), s, sa, t0, t1, cnt_cap);
+        ctx->fill_parity ^= 1;        // only now: both launches are enqueued, so the other set WILL be zeroed for the next build (an error return above leaves the parity alone)
         if (do_prof2) {
-            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
             const double nb = h[7] > 0 ? (double)h[7] * 100.0 : 100.0;
             fprintf(stderr, "[sort2 prof] blocks %lld | mean us per block: head %.2f  load+rank %.2f  scan %.2f  place %.2f  copies %.2f  drain %.2f\n",
                     h[7], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb);
@@ -410,7 +471,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             hipLaunchKernelGGL(k_bucket_onepass<T>, dim3(c0 + c1), dim3(kBkThreads), 0, s, s0, s1, c0, do_prof ? prof1 : nullptr,
                                bs[0] == &a ? g0 : g1, nbs > 1 ? g1 : (bs[0] == &a ? g0 : g1));
             if (do_prof) {
-                long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof1, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+                long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof1, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
                 const double nb = h[7] > 0 ? (double)h[7] : 1.0;
                 fprintf(stderr, "[onepass prof] blocks %lld | mean us per block: zero+loads %.2f  keys+LDS ranks %.2f  slot reservations %.2f  stores %.2f\n", h[7],
                         h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0);
@@ -423,17 +484,15 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         const int t0 = bs[0]->nb_max, t1 = nbs > 1 ? bs[1]->nb_max : 0;
         const int cnt_cap = 1 << std::max(bs[0]->shift, nbs > 1 ? bs[1]->shift : 0);
         const size_t lds = bucket_sort_lds_bytes<T>(cnt_cap);
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[sizeof(T) == 4 ? 0 : 1]) {
+        static std::atomic<unsigned long long> attr_set[2];
+        if (attr_unset_here(attr_set[sizeof(T) == 4 ? 0 : 1]))
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
-            attr_set[sizeof(T) == 4 ? 0 : 1] = true;
-        }
         // One launch for both clouds, like the other passes (1024 threads / 4096-point buckets: all blocks of both clouds are
         // resident at once; measured 0.174 vs 0.186 ms per step against one launch per cloud).
         hipLaunchKernelGGL(k_bucket_sort<T>, dim3(t0 + t1), dim3(kSortThreads), lds, s, s0, s1, t0, do_prof ? prof : nullptr, cnt_cap);
         if (do_prof) {
-            long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s));
+            long long h[8]; HIP_TRY(hipMemcpyAsync(h, prof, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
             const double nb = h[7] > 0 ? (double)h[7] : 1.0;
             fprintf(stderr, "[bucket_sort prof] blocks %lld | mean us per block: head %.2f  zero+sync %.2f  load+rank %.2f  scan %.2f  place %.2f\n", h[7],
                     h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0, h[4] / nb / 100.0);
@@ -839,9 +898,8 @@ static int kd_finish_max() {
 }
 template <typename T>
 static hipError_t kd_subtree_attr() {
-    static bool attr_set = false;
-    if (attr_set) return hipSuccess;
-    attr_set = true;
+    static std::atomic<unsigned long long> attr_set;
+    if (!attr_unset_here(attr_set)) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_subtree<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kd_sub_lds_bytes<T>());
 }
 template <typename T>
@@ -995,7 +1053,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
                 sub_launched = true;
             } else {
                 HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_WAIT(s);
             }
         } else {
         int pairs = std::max(1, (expected + 1) / 2 - levels_done / 2);
@@ -1005,7 +1063,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
             if (hcnt[b.n_cur - counters] == 0) break;      // after an even number of levels the roles are as at the start
             pairs = 1;
         }
@@ -1019,7 +1077,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     // finish every small node inside one workgroup's LDS (the level loop's last read-back already holds the count)
     if (!(M > b.sub_max)) {
         HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
     }
     const int n_sub = sub_launched ? 0 : hcnt[4];
     if (n_sub > 0) {
@@ -1030,7 +1088,7 @@ static int kd_build_device(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* d_
     if (max_depth_out) *max_depth_out = counters + 5;
     if (!need_depth && !b.prof && !n_real_out) { *levels_out = 0; return 0; }      // (the caller sizes its stacks by a bound: one host round trip less)
     HIP_TRY(hipMemcpyAsync(hcnt, counters, sizeof hcnt, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_WAIT(s);
     *levels_out = hcnt[5] + 1;      // tree depth (root = 0) + 1
     if (b.prof) {
         long long hp[16]; HIP_TRY(hipMemcpy(hp, b.prof, sizeof hp, hipMemcpyDeviceToHost));
@@ -1100,7 +1158,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         HIP_TRY(hipGetLastError());
         int hc[16] = {0};                  // the build's counters: [3] = the traversal's error flag, [9] = a node held elements equal to its cut value
         HIP_TRY(hipMemcpyAsync(hc, err - 3, sizeof hc, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         if (hc[9] && !c->kd_need_ph2) {     // top levels ran without planeSplit's second loop and needed it (kd_build_device, regions of
             c->kd_need_ph2 = true;          // interest: no read-back before the traversal): once more, the context remembers
             --attempt; continue;
@@ -1116,13 +1174,13 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
             hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
         }
         if (herr == 2 && attempt == 0) continue;
         if (herr) return fail(PCU_HIP_ERR_RUNTIME, "internal: kd tie-order traversal exceeded the tree depth (%d)", levels);
         break;
     }
-    if (timed) { (void)hipEventRecord(e1, s); HIP_TRY(hipStreamSynchronize(s)); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
+    if (timed) { (void)hipEventRecord(e1, s); HIP_WAIT(s); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); st->ms_tie += ms; }
     return 0;
 }
 
@@ -1219,7 +1277,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         c->eager_large = true;                   // data of this kind will come again (mesh samples: +0.18 ms per call for the round trip)
         if (search_enqueue(c, s, j, st)) return -1;
         HIP_TRY(hipMemcpyAsync(hc_large, j.sc.counters, sizeof hc_large, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         hc = hc_large; redone = true;
     }
     if (hc[C_SKEW] && rescale_wanted(c, j, s, hc[C_SKEW])) return 3;          // 3: restart the call at another grid resolution
@@ -1258,7 +1316,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
             if (search_enqueue(c, s, j, st)) return -1;
             HIP_TRY(hipMemcpyAsync(hs, hs_dev, sizeof hs, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
             keep_base = hs[1] <= 0.5 * (double)j.ridx.n;
             if (!keep_base && st) *st = before;          // (the attempt is dropped: its builds and passes are not the call's)
             if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d heavy points %.0f, level cells %.0f: %s\n", j.ridx.n, hs[1], hs[0], keep_base ? "grid kept" : "base refit");
@@ -1268,7 +1326,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
             if (core_range_enqueue(ar, j.ridx, j.d_ref_pts, s, &qs)) return -1;
             if (index_build_refit(ar, base, j.ridx, j.d_ref_pts, qs, (double)j.ridx.n / j.occ, s)) return -1;
             HIP_TRY(hipMemcpyAsync(&hb, base.gp, sizeof hb, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
             if (st) st->n_grid_builds += 1;
             j.ridx = base; j.n_fine = 0;
             if ((double)hb.sumsq / (double)j.ridx.n > 4.0 * (j.occ + 1.0)) {       // still unbalanced after clipping the outliers
@@ -1276,7 +1334,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
             }
             if (search_enqueue(c, s, j, st)) return -1;
             HIP_TRY(hipMemcpyAsync(hc_redo, j.sc.counters, sizeof hc_redo, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
         }
         hc = hc_redo; redone = true;
         if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[skew] n=%d lists: after finest %d, after mid %d, after base %d; ties %d\n", j.qidx.n, hc[C_X0], hc[C_X1], hc[C_U1], hc[C_T1]);
@@ -1321,7 +1379,7 @@ static int search_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>&
         if (launch_search_wave<T>(KL, b, s)) return -1;
         int left = 0;
         HIP_TRY(hipMemcpyAsync(&left, j.sc.counters + C_SPARE, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         if (st) st->n_passes++;
         n_left = left;
         int* done = cur; cur = nxt; nxt = done;
@@ -1406,7 +1464,7 @@ template <typename T>
 static int check_nonfinite(const GridParams<T>* gp, int mask, hipStream_t s) {
     int nf = 0;
     HIP_TRY(hipMemcpyAsync(&nf, reinterpret_cast<const char*>(gp) + offsetof(GridParams<T>, nonfinite), sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_WAIT(s);
     return (nf & mask) ? nonfinite_error(false) : 0;
 }
 // k beyond the grid search's capacity (k > 127): the reference's own algorithm for every query -- its kd-tree, rebuilt on the GPU
@@ -1452,12 +1510,9 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
         a.stack_cap = levels + 2;
         if ((rc = aalloc(ar, &frames, (size_t)grid * a.stack_cap))) break;
         a.stack = frames;
-        static bool attr_set[2] = {false, false};
-        const int ti = sizeof(T) == 4 ? 0 : 1;
-        if (!attr_set[ti]) {
+        static std::atomic<unsigned long long> attr_set[2];
+        if (attr_unset_here(attr_set[sizeof(T) == 4 ? 0 : 1]))
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_search_all<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr_set[ti] = true;
-        }
         hipLaunchKernelGGL(k_kd_search_all<T>, dim3(grid), dim3(64), rs_lds ? slot_bytes : 0, s, a);
         HIP_TRY(hipGetLastError());
         int herr = 0;
@@ -1466,7 +1521,7 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         if (herr) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: kd traversal exceeded the tree depth (%d)", levels); break; }
         if (st) { st->n_queries = nq; st->n_passes = 1; }
     } while (0);
@@ -1551,7 +1606,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         if (row_out) { hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError()); }
         else if ((rc = unpermute_enqueue(s, job, dd, di, rb, c->h_pinned, ++c->seq))) break;   // optimistic: redone below if stragglers / ties remain
         tm.mark(2);
-        HIP_TRY(hipStreamSynchronize(s));         // the per-row outputs must be complete, so this call waits for the stream, not for the word
+        HIP_WAIT(s);         // the per-row outputs must be complete, so this call waits for the stream, not for the word
         if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
         if (job.ridx.lean || job.qidx.lean) {
             const int* hc0 = ((ResultBlock*)c->h_pinned)->counters[0];
@@ -1564,7 +1619,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
             if ((hc0[C_U1] > 0 || hc0[C_T1] > 0) && !hc0[C_SKEW] && !hc0[C_LARGE]) {       // stragglers beyond radius 2, possible ties, deferred lanes: the wave pass now
                 if ((rc = search_enqueue(c, s, job, st, false, 2))) break;
                 hipLaunchKernelGGL(k_result_block_to_host, dim3(1), dim3(64), 0, s, reinterpret_cast<const int*>(rb), c->h_pinned, ++c->seq); HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_WAIT(s);
                 if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) { rc = fail(PCU_HIP_ERR_RUNTIME, "internal: the result block did not arrive"); break; }
             }
         }
@@ -1583,7 +1638,7 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         if (st) { st->n_queries = nq; st->ms_index = tm.span(0, 1); st->ms_search = tm.span(1, 2); st->ms_total = tm.span(0, 2); collect_kernel_times(c, st); }
     } while (0);
     kd_speculate_end(c, rc != PCU_RETRY);
@@ -1764,10 +1819,13 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 0;; ++it) {
             if ((unsigned)*flag == c->seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
-            if ((it & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // long call or fault: block instead
+            if ((it & 0x3ff) == 0x3ff) {
+                if (cancel_requested()) return cancelled();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // long call or fault: poll the stream instead
+            }
         }
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_WAIT(s);
     if ((unsigned)*(volatile int*)(c->h_pinned + 63) != c->seq) return fail(PCU_HIP_ERR_RUNTIME, "internal: the epilogue kernel did not deliver its result block");
     return 0;
 }
@@ -1845,7 +1903,7 @@ static int pair_nonfinite_flags(hipStream_t s, const PairState<T>& P, int (&nf)[
     const GridParams<T>* gp[2] = {P.xy.qidx.gp, P.xy.ridx.gp};
     for (int d = 0; d < 2; ++d)
         HIP_TRY(hipMemcpyAsync(&nf[d], reinterpret_cast<const char*>(gp[d]) + offsetof(GridParams<T>, nonfinite), sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_WAIT(s);
     return 0;
 }
 // ... and is it input the reference answers stably (see nonfinite_error)? Then the jobs take it from here on (row-based path).
@@ -1883,7 +1941,8 @@ static bool skew_prelaunch_wanted(const pcu_hip_ctx* c, const SearchJob<T>& j, c
 template <typename T>
 static int skew_prelaunch(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, pcu_hip_stats* st, SkewPre& pre) {
     const int p0 = st ? st->n_passes : 0, b0 = st ? st->n_grid_builds : 0;
-    index_large_pass<T>(j.qidx, &j.ridx, s);
+    // (no index_large_pass here: skew_prelaunch_wanted requires C_LARGE == 0, i.e. no deferred buckets in either index -- and the two directions run
+    // this function side by side on two streams over the SAME two indexes with the roles swapped, where a placement pass would race with itself)
     j.skew_check = false;
     const double* hs_dev = nullptr;
     if (skew_add_levels(ar, s, j, st, j.ridx, &hs_dev)) return -1;
@@ -1899,7 +1958,7 @@ template <typename T>
 static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock* host, bool copied_by_kernel = false,
                        bool host_given = false) {
     if (host_given) {}                          // (*host holds the counters to act on: nothing was enqueued since they were read)
-    else if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); }
+    else if (!copied_by_kernel) { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_WAIT(s); }
     else if (wait_result_block(c, s)) return -1;
     if (!host_given) memcpy(host, c->h_pinned, sizeof(ResultBlock));
     // Both directions unbalanced (clustered clouds): their refits -- dozens of short launches each -- are enqueued side by side on the
@@ -1919,7 +1978,7 @@ static int pair_finish(pcu_hip_ctx* c, Arena& ar, hipStream_t s, PairState<T>& P
             HIP_TRY(hipMemcpyAsync(hp + 16 * d, pre[d].hs_dev, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(hp + 32 + sizeof(int) * C_N * d, (d ? P.yx : P.xy).sc.counters, sizeof(int) * C_N, hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         for (int d = 0; d < 2; ++d) { memcpy(pre[d].hs, hp + 16 * d, 16); memcpy(pre[d].hc_redo, hp + 32 + sizeof(int) * C_N * d, sizeof(int) * C_N); }
     }
     int r1 = search_finish(c, ar, s, P.xy, st, host->counters[0], &pre[0]);
@@ -2011,7 +2070,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 if (!given && (rc = argmax_enqueue(c, s, P, two_sided))) break;
                 tm.mark(3);
                 if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true, given); if (rc == PCU_NONFINITE) rc = nonfinite_error(true); if (given && rc == 0) rc = 1; if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }   // syncs; 1 => redo epilogue
-                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
+                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_WAIT(s); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc) break;
             // The value never depends on the order of exact ties, and (i, j) only does if the arg-max source row i itself
@@ -2028,7 +2087,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 HIP_TRY(hipGetLastError());
                 int hit[2] = {0, 0};
                 HIP_TRY(hipMemcpyAsync(hit, P.tie_hit, sizeof hit, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_WAIT(s);
                 bool redo = false;
                 for (int dir = 0; dir < (two_sided ? 2 : 1) && !rc; ++dir) {
                     SearchJob<T>& J = dir ? P.yx : P.xy;
@@ -2040,7 +2099,7 @@ static int hausdorff_end(pcu_hip_ctx* c, PendingPair<T>& pp, T* out_d, int64_t* 
                 if (redo) {
                     if ((rc = argmax_enqueue(c, s, P, two_sided))) break;
                     HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_WAIT(s);
                     memcpy(&host, c->h_pinned, sizeof host);
                 }
             }
@@ -2160,13 +2219,13 @@ static int chamfer_end(pcu_hip_ctx* c, PendingPair<T>& pp, double* out_mean2) {
                 HIP_TRY(hipGetLastError());
                 tm.mark(3);
                 if (attempt == 0) { rc = pair_finish(c, ar, s, P, st, &host, /*copied_by_kernel=*/true); if (rc == PCU_NONFINITE) { rc = refused(); break; } if (rc == 3) rc = PCU_RETRY; if (rc <= 0 || rc == PCU_RETRY) break; rc = 0; }
-                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_TRY(hipStreamSynchronize(s)); memcpy(&host, c->h_pinned, sizeof host); }
+                else { HIP_TRY(hipMemcpyAsync(c->h_pinned, P.rb, sizeof(ResultBlock), hipMemcpyDeviceToHost, s)); HIP_WAIT(s); memcpy(&host, c->h_pinned, sizeof host); }
             }
             if (rc || nan_result) break;
             if (!on_dev) {
                 if (out_cxy) HIP_TRY(hipMemcpyAsync(out_cxy, P.xy.out_i, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
                 if (out_cyx) HIP_TRY(hipMemcpyAsync(out_cyx, P.yx.out_i, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_WAIT(s);
             }
         }
         const double* hs = host.sums;
@@ -2244,7 +2303,7 @@ static int normals_knn_impl(pcu_hip_ctx* c, const T* points, int64_t n, const T*
         HIP_TRY(hipMemcpyAsync(out_n, d_out, (size_t)n * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out_keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_WAIT(s);
     return 0;
 }
 // estimate_point_cloud_normals_ball_internal (:305-372): every point inside the ball (radiusSearch semantics of :75, see normals.h).
@@ -2285,7 +2344,7 @@ static int normals_ball_impl(pcu_hip_ctx* c, const T* points, int64_t n, const T
             HIP_TRY(hipMemcpyAsync(out_n, d_out, (size_t)n * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_keep, d_keep, (size_t)n, hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -2446,6 +2505,19 @@ int pcu_hip_device_count(void) {
     return n;
 }
 
+void pcu_hip_cancel(void) { g_cancel.store(1, std::memory_order_relaxed); }
+int pcu_hip_watch_sigint(int enable) {
+    if (enable && !g_sigint_watched.exchange(1)) {
+        struct sigaction sa; memset(&sa, 0, sizeof sa);
+        sa.sa_sigaction = pcu_on_sigint; sa.sa_flags = SA_SIGINFO | SA_RESTART; sigemptyset(&sa.sa_mask);
+        if (sigaction(SIGINT, &sa, &g_prev_sigint) != 0) { g_sigint_watched.store(0); return fail(PCU_HIP_ERR_RUNTIME, "sigaction(SIGINT) failed"); }
+    } else if (!enable && g_sigint_watched.exchange(0)) {
+        struct sigaction cur;
+        // (only if ours is still the installed handler: somebody who installed theirs after us keeps it)
+        if (sigaction(SIGINT, nullptr, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == pcu_on_sigint) (void)sigaction(SIGINT, &g_prev_sigint, nullptr);
+    }
+    return 0;
+}
 int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     if (!out_ctx) return fail(PCU_HIP_ERR_INVALID, "null out_ctx");
     int n = pcu_hip_device_count();

@@ -546,6 +546,13 @@ __global__ __launch_bounds__(kBlock) void k_search(const SearchArgs<T> a) {
 //     against a minimum that may be one group stale -- still a valid bound -- when a lane moves to its next run); the cell
 //     cuts are those decided after the centre row.
 // Only for open indexes (closed sub-box levels have no sentinel behind their last record).
+// The query's cell along one axis, as cell_coord (pcu_types.h) gives it: for float the clamp is one v_med3 before the conversion instead of two
+// compare + select pairs behind it (t in [0, G - 1] converts to itself truncated, everything above to G - 1, everything below -- and NaN -- to 0).
+__device__ __forceinline__ int cell_of_query(const GridParams<float>& g, const int axis, const float v) {
+    const float t = (v - g.org[axis]) * g.inv_h;
+    return (int)__builtin_amdgcn_fmed3f(t, 0.f, (float)(g.G[axis] - 1));
+}
+__device__ __forceinline__ int cell_of_query(const GridParams<double>& g, const int axis, const double v) { return grid_cell(g, axis, v); }
 template <typename T> struct K1Group { static constexpr int n = 4; };     // records per group (8 measured slower: more bytes gathered past the row ends)
 struct __attribute__((packed, aligned(4))) CellStart4 { unsigned v[4]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -580,7 +587,19 @@ template <typename T> __device__ __forceinline__ T lb_unpack(unsigned b) { retur
 constexpr bool kFlatXyz = PCU_FLAT_XYZ != 0;
 
 template <typename T> struct __attribute__((packed, aligned(4))) Group12 { T v[12]; };      // 4 records of a coordinates-only stream
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// record index -> byte offset in the candidate stream: shifts and one add (v_mul_lo_u32 is a quarter-rate instruction, and a 24-bit multiply
+// does not reach the 2^27 - 16 records an index may hold)
+template <unsigned REC> __device__ __forceinline__ unsigned rec_bytes(unsigned i) {
+    static_assert(REC == 12u || REC == 24u || REC == 16u || REC == 32u, "record sizes of the candidate streams");
+    if (REC == 16u) return i << 4;
+    if (REC == 32u) return i << 5;
+    unsigned r; const unsigned t = REC == 12u ? i << 2 : i << 3;      // (as inline assembly: the compiler folds the C expression back into the multiply)
+    if (REC == 12u) asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(i), "v"(t));
+    else asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(r) : "v"(i), "v"(t));
+    return r;
+}
+// a * b + c with 24-bit unsigned factors, one full-rate instruction (the compiler widens the C expression to a 64-bit multiply-add when it cannot prove the ranges)
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // One group = 4 consecutive records of the candidate stream: `load` requests it (straight-line loads), `dists` gives the 4 squared
 // distances (bit-identical to 4 x dist2: IEEE subtract, multiply, add in the reference's order).
@@ -645,9 +664,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         q.idx = FUSE == FUSE_SUM ? 0 : a.q_idx[qpos];
     }
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
-    const int ccx = grid_cell(g, 0, q.x), ccy = grid_cell(g, 1, q.y), ccz = grid_cell(g, 2, q.z);
-    const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, Gx - 1);
-    const int len = x1 - x0 + 1;                      // cells per row run: 3, 2 at a grid border (1 if Gx == 1)
+    const int ccx = cell_of_query(g, 0, q.x), ccy = cell_of_query(g, 1, q.y), ccz = cell_of_query(g, 2, q.z);
     constexpr unsigned kRec = GE::kRec;               // bytes per record of the candidate stream
     constexpr int kG = K1Group<T>::n;
     const char* const base = XYZ ? reinterpret_cast<const char*>(a.ref_xyz) : reinterpret_cast<const char*>(a.ref);
@@ -666,40 +683,62 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         best = lt_ ? m_ : best;                                                                              \
         boff = lt_ ? (OFF) : boff;                                                                           \
     }
-    auto row_table = [&](int j, bool& ok, bool& odd) {
-        const int cy = ccy + kRowOy[j], cz = ccz + kRowOz[j];
-        ok = cy >= 0 && cy < Gy && cz >= 0 && cz < Gz;
-        // rows < 2^22, cells per row <= 2048, cells < 2^26: a 24-bit multiply (full rate) and a 32-bit byte offset from the uniform base
-        const unsigned row = (unsigned)(ok ? cz : ccz) * (unsigned)Gy + (unsigned)(((ok ? cz : ccz) & 1) ? Gy - 1 - (ok ? cy : ccy) : (ok ? cy : ccy));
-        odd = row & 1u;
-        const unsigned lo = __umul24(row, (unsigned)Gx) + (unsigned)(odd ? Gx - 1 - x1 : x0);
-        return *reinterpret_cast<const CellStart4*>(reinterpret_cast<const char*>(a.cell_start) + (size_t)(lo * 4u));
+    // ---- the nine row tables. Round 5: the per-query part of this kernel was 680 of its 1180 vector instructions per wave (428 of them
+    // here: nine table addresses with their clamps, snake-order selects and run-length cases, and the cut decisions made on the *results*
+    // of per-row comparisons), the candidate loops ~500. What every row shares is now computed once per query:
+    //   * the x direction of a row is (cy ^ cz) & 1 (pcu_types.h: grid_row / row_run_lo; the parity of the linear row number whatever Gy is),
+    //     so a row either runs like the centre row (|oy| + |oz| even) or against it: two table offsets, and the two sides of the query's cell
+    //     (A = the side met first in a row that runs like the centre row, B = the other) are swapped on the *inputs* of the cut tests;
+    //   * the linear numbers of the nine rows are three bases and a per-query step of +-1 (the y order flips with cz);
+    //   * a row's table is ALWAYS the four words {start of the cell before the query's, start of its own, of the next one, end of that}: at a
+    //     grid border the missing cell's word belongs to the neighbouring row (or, before the first row, to the padding behind GridParams:
+    //     index_alloc) and is never used -- a missing cell counts as cut -- so there are no run-length cases and no clamped cell range.
+    // The arithmetic of the bounds (and with it what is scanned and what is certified) is unchanged.
+    const bool hasxl = ccx > 0, hasxh = ccx < Gx - 1;
+    const bool odd0 = ((ccy ^ ccz) & 1) != 0, zodd = (ccz & 1) != 0;
+    const bool hasA = (odd0 && hasxh) || (!odd0 && hasxl), hasB = (odd0 && hasxl) || (!odd0 && hasxh);      // (mask logic: scalar unit)
+    const unsigned Gx4 = (unsigned)Gx << 2;           // byte strides of the table (cells per row <= 2048, rows < 2^22: 24-bit multiplies)
+    const unsigned xe4 = (unsigned)ccx << 2, xo4 = (unsigned)(Gx - 1 - ccx) << 2;     // (+1 cell: the base below is one word before the table)
+    const unsigned xS4 = odd0 ? xo4 : xe4, xR4 = odd0 ? xe4 : xo4;                    // rows that run like the centre row / against it
+    const int yS = zodd ? Gy - 1 - ccy : ccy, sS = zodd ? -1 : 1;                     // y position inside the query's z slab, and the slab's y step
+    const int row0 = (int)mad24((unsigned)ccz, (unsigned)Gy, (unsigned)yS);
+    const int flip = (Gy - 1 - yS) - yS;                                              // the neighbouring slabs count y the other way round
+    const int rowM = row0 + flip - Gy, rowP = row0 + flip + Gy;
+    const bool okyM = ccy > 0, okyP = ccy < Gy - 1, okzM = ccz > 0, okzP = ccz < Gz - 1;
+    const char* const tbase = reinterpret_cast<const char*>(a.cell_start) - 4;
+    auto row_table = [&](int j, bool& ok) {
+        const int oy = kRowOy[j], oz = kRowOz[j];
+        ok = (oy == 0 || (oy < 0 ? okyM : okyP)) && (oz == 0 || (oz < 0 ? okzM : okzP));
+        const int rr = oz == 0 ? row0 + oy * sS : (oz < 0 ? rowM : rowP) - oy * sS;
+        const unsigned row = (unsigned)(ok ? rr : row0);                              // (a row outside the grid: any valid address, the row is dropped below)
+        return *reinterpret_cast<const CellStart4*>(tbase + (size_t)(__umul24(row, Gx4) + (((oy + oz) & 1) == 0 ? xS4 : xR4)));
     };
-    bool okj[9], oddj[9];
+    bool okj[9];
     CellStart4 tb[9];
-    tb[0] = row_table(0, okj[0], oddj[0]);
+    tb[0] = row_table(0, okj[0]);
     if (EARLY) {
 #pragma unroll
-        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j]);
     }
     // ---- centre row: whole run
-    const unsigned cnt0 = (len == 3 ? tb[0].v[3] : (len == 2 ? tb[0].v[2] : tb[0].v[1])) - tb[0].v[0];
+    const unsigned c_s = hasA ? tb[0].v[0] : tb[0].v[1], c_e = hasB ? tb[0].v[3] : tb[0].v[2];
+    const unsigned cnt0 = c_e - c_s;
     bool defer = cnt0 > cand_cap;
     {
-        const unsigned o0 = tb[0].v[0] * kRec;
-        const unsigned o1 = (defer || !valid) ? o0 : o0 + cnt0 * kRec;
+        const unsigned o0 = rec_bytes<kRec>(c_s);
+        const unsigned o1 = (defer || !valid) ? o0 : rec_bytes<kRec>(c_e);
         for (unsigned off = o0; off < o1; off += (unsigned)kG * kRec) { const typename GE::Raw raw = GE::load(base, off); PCU_K1_EVAL(raw, off) }
     }
     // ---- the other rows: cut runs that survive the centre row's minimum -> this lane's list
     if (!EARLY) {
 #pragma unroll
-        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j], oddj[j]);
+        for (int j = 1; j < 9; ++j) tb[j] = row_table(j, okj[j]);
     }
     const T shrink = (T)1 - (T)4 * Limits<T>::eps;
     T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
     T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
     const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
-    const bool has_lo = x0 < ccx, has_hi = x1 > ccx;
+    const T mA2 = odd0 ? mxh2 : mxl2, mB2 = odd0 ? mxl2 : mxh2;
     T my2[3], mz2[3];
     {
         T m;
@@ -709,26 +748,27 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
         m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
     }
+    // (the cap on a lane's serial work counts what the lane would scan: the centre row and the cut runs it lists)
     unsigned total = cnt0;
-#pragma unroll
-    for (int j = 1; j < 9; ++j) total += okj[j] ? (len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1])) - tb[j].v[0] : 0u;
-    defer = defer || total > cand_cap;
     int n = 0;
 #pragma unroll
     for (int j = 1; j < 9; ++j) {
-        const T ry = my2[kRowOy[j] == 0 ? 0 : (kRowOy[j] < 0 ? 1 : 2)], rz = mz2[kRowOz[j] == 0 ? 0 : (kRowOz[j] < 0 ? 1 : 2)];
-        const T rlb = ry + rz;                                      // = ((0) + (my*my)) + (mz*mz), see row_lower_bounds
-        const bool cut_lo = has_lo && best < ((mxl2 + ry) + rz), cut_hi = has_hi && best < ((mxh2 + ry) + rz);
-        const bool cut_first = oddj[j] ? cut_hi : cut_lo, cut_last = oddj[j] ? cut_lo : cut_hi;
-        const unsigned s_run = cut_first ? tb[j].v[1] : tb[j].v[0];
-        const unsigned e_full = len == 3 ? tb[j].v[3] : (len == 2 ? tb[j].v[2] : tb[j].v[1]);
-        const unsigned e_cut = len == 3 ? tb[j].v[2] : (len == 2 ? tb[j].v[1] : tb[j].v[0]);
-        const unsigned e_run = cut_last ? e_cut : e_full;
-        if (valid && okj[j] && !defer && !(best < rlb) && e_run > s_run) {
-            s_rng[n][tid] = make_uint2(s_run * kRec, ((e_run - s_run) << 16) | lb_pack(rlb));
-            ++n;
-        }
+        const int oy = kRowOy[j], oz = kRowOz[j];
+        const T ry = my2[oy == 0 ? 0 : (oy < 0 ? 1 : 2)], rz = mz2[oz == 0 ? 0 : (oz < 0 ? 1 : 2)];
+        const bool same = ((oy + oz) & 1) == 0;
+        const T mF2 = same ? mA2 : mB2, mL2 = same ? mB2 : mA2;      // the squared x margins of the run's first / last cell
+        const bool hasF = same ? hasA : hasB, hasL = same ? hasB : hasA;
+        // lower bounds ((mx*mx) + (my*my)) + (mz*mz) in the distance's own operation order; a zero term is left out (x + 0 == x for x >= +0)
+        const T rlb = oy == 0 ? rz : (oz == 0 ? ry : ry + rz);
+        const T bF = oy == 0 ? mF2 + rz : (oz == 0 ? mF2 + ry : (mF2 + ry) + rz), bL = oy == 0 ? mL2 + rz : (oz == 0 ? mL2 + ry : (mL2 + ry) + rz);
+        const bool cutF = !hasF || best < bF, cutL = !hasL || best < bL;
+        const unsigned s_run = cutF ? tb[j].v[1] : tb[j].v[0], e_run = cutL ? tb[j].v[2] : tb[j].v[3];
+        const bool take = okj[j] && !defer && !(best < rlb) && e_run > s_run;
+        s_rng[n][tid] = make_uint2(rec_bytes<kRec>(s_run), ((e_run - s_run) << 16) | lb_pack(rlb));       // (slot n is overwritten until a run is taken)
+        n += take ? 1 : 0;
+        total += take ? e_run - s_run : 0u;
     }
+    if (total > cand_cap) { defer = true; n = 0; }
     const int own = tid;
     int r = 0;
     unsigned off = 0, end = 0;
@@ -738,7 +778,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         while (r < n) {
             const uint2 e = s_rng[r][own];
             ++r;
-            if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + (e.y >> 16) * kRec; live = true; break; }
+            if (!(best < lb_unpack<T>(e.y & 0xffffu))) { off = e.x; end = e.x + __umul24(e.y >> 16, kRec); live = true; break; }
         }
     };
     next_run();
@@ -770,13 +810,25 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     // wave for longer than the rest of the launch takes -- measured: +19 us), every lane scans its row from scratch against the broadcast query,
     // a wave reduction picks the winner, and the query is certified against that box. The wave pass is launched only when a call's lists are not
     // empty afterwards (pcu_hip.hip: fused_wave_if_needed, knn_attempt). Waves with exited lanes (the last of a cloud) leave their stragglers to it.
-    int cx0 = x0, cx1 = x1;                              // the box of cells the result is certified against
-    int cy0 = max(ccy - 1, 0), cy1 = min(ccy + 1, Gy - 1), cz0 = max(ccz - 1, 0), cz1 = min(ccz + 1, Gz - 1);
-    T lb = (T)0;                                         // the certification bound of that box
+    // Certification. Round 5: every face of the 27-cell box that exists lies at least one cell edge away from the query, less the face slacks and
+    // the rounding of the face positions -- the query's own cell is bounded by face_above(c - 1) <= q < face_below(c + 1) (pcu_types.h), the box
+    // by face_below(c - 1) / face_above(c + 1) -- so `quick` below, a grid-wide constant, is a lower bound of the exact bound of EVERY query
+    // (same shrink, same squaring: monotone). A wave whose lanes all pass it skips the six face distances (88 vector instructions per wave; at two
+    // points per cell 4 lanes in 10,000 fail it); the others compute the exact bound as before and may rescue their stragglers.
+    T lb;                                                // the certification bound of the box the lane's result is checked against
+    {
+        const T smax = g.slack[0] > g.slack[1] ? (g.slack[0] > g.slack[2] ? g.slack[0] : g.slack[2]) : (g.slack[1] > g.slack[2] ? g.slack[1] : g.slack[2]);
+        const T mag = ((fabs(g.org[0]) + fabs(g.org[1])) + fabs(g.org[2])) + (T)(Gx + Gy + Gz + 3) * g.h + smax;      // bounds every face position
+        const T hq = (g.h - (T)2 * smax) - (T)16 * Limits<T>::eps * mag;
+        const T hs = hq > (T)0 ? hq * shrink : (T)0;
+        lb = hs * hs;
+    }
 #ifndef PCU_NO_RESCUE
 #define PCU_NO_RESCUE 0
 #endif
-    {
+    if (__ballot(valid && !defer && !(best < lb)) != 0ull) {
+        const int cx0 = max(ccx - 1, 0), cx1 = min(ccx + 1, Gx - 1);
+        const int cy0 = max(ccy - 1, 0), cy1 = min(ccy + 1, Gy - 1), cz0 = max(ccz - 1, 0), cz1 = min(ccz + 1, Gz - 1);
         lb = face_lower_bound_inner(g, q.x, q.y, q.z, cx0, cx1, cy0, cy1, cz0, cz1);
         unsigned long long todo = __ballot(valid && !defer && !(best < lb));
         // (more than a few of them in one wave is not bad luck but the shape of the input -- a query cloud away from the dataset, every lane
@@ -817,7 +869,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
                 for (int o = 32; o > 0; o >>= 1) { const T ot = __shfl_xor(mn, o, 64); mn = ot < mn ? ot : mn; }
                 const T lb2 = face_lower_bound_inner(g, sq.x, sq.y, sq.z, bx0, bx1, by0, by1, bz0, bz1);
                 if (FUSE == FUSE_SUM) {                                       // (the sum needs the value only)
-                    if (lane_ == l) { best = mn; lb = lb2; cx0 = bx0; cx1 = bx1; cy0 = by0; cy1 = by1; cz0 = bz0; cz1 = bz1; }
+                    if (lane_ == l) { best = mn; lb = lb2; }
                     continue;
                 }
                 const unsigned long long eqm = __ballot(wbest == mn && wboff != 0xffffffffu);
@@ -832,14 +884,12 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
                 const bool rtie = many || any_tie, rtie2 = (many && __popcll(eqm) > 2) || any_tie2 || (many && any_tie);
                 if (lane_ == l) {
                     best = mn; lb = lb2; boff = eqm ? rb : 0xffffffffu; toff = rt; tie = rtie; tie2 = rtie2;
-                    cx0 = bx0; cx1 = bx1; cy0 = by0; cy1 = by1; cz0 = bz0; cz1 = bz1;
                 }
             }
         }
     }
 #undef PCU_K1_EVAL
     // ---- which record of the winning group it was; ties (see k_search1)
-    T bd[1] = {best};
     int bi[1] = {0x7fffffff};
     auto which = [&](unsigned goff, int& hits, unsigned& rec_off) {         // records of the group at `goff` whose d2 equals the minimum
         T d_[4]; GE::dists(GE::load(base, goff), q, d_);
@@ -862,7 +912,20 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
             if (h2 == 1 && ro2 == ro) tie = false;        // the same record met twice (groups run past their run's end)
         }
     }
-    if (FUSE == FUSE_NONE) { finish_lane<T, 1>(a, g, q, qpos, cx0, cx1, cy0, cy1, cz0, cz1, bd, bi, tie, valid, defer); return; }
+    if (FUSE == FUSE_NONE) {                              // result rows (finish_lane for k = 1, with the bound computed above)
+        if (defer) { wave_append(valid, qpos, a.ties, a.n_ties); return; }       // nothing was scanned: the wave-per-query pass at the same radius takes over
+        const bool certified = valid && best < lb;
+        if (certified) {
+            const size_t o = (size_t)(a.row_out ? (int)q.idx : qpos) * (size_t)a.kreq;
+            const bool found = bi[0] != 0x7fffffff;
+            a.out_i[o] = found ? (long long)bi[0] : -1ll;
+            a.out_d[o] = found ? (a.squared ? best : sqrt(best)) : (T)-1;
+        }
+        const int us = wave_append(valid && !certified, qpos, a.unresolved, a.n_unresolved);
+        if (us >= 0 && a.ubound) a.ubound[us] = best;
+        wave_append(certified && tie, qpos, a.ties, a.n_ties);
+        return;
+    }
     // fused epilogue: the lane's distance goes into the block's partial (kernel wrapper) instead of a result row
     if (defer) {                 // nothing was scanned: the wave-per-query pass at the same radius takes over
         wave_append(valid, qpos, a.ties, a.n_ties);

@@ -41,7 +41,7 @@ static int morton_map_impl(pcu_hip_ctx* c, int kind, const In* in, const In2* in
         else hipLaunchKernelGGL((k_morton_addsub<In, In2>), dim3(blocks), dim3(256), 0, s, d_in, d_in2, (long long)n, kind == 3 ? 1 : 0, (uint64_t*)d_out);
         HIP_TRY(hipGetLastError());
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -65,7 +65,7 @@ static int morton_knn_impl(pcu_hip_ctx* c, const C* codes, int64_t n, const C* q
         hipLaunchKernelGGL((k_morton_knn<C>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_codes, (long long)n, d_q, (long long)m, k, sort_dist, d_nn);
         HIP_TRY(hipGetLastError());
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out_nn, d_nn, (size_t)m * k * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -161,12 +161,12 @@ static int voxel_downsample_impl(pcu_hip_ctx* c, const T* pts, int64_t n, const 
         HIP_TRY(hipGetLastError());
         unsigned n_out = 0;
         HIP_TRY(hipMemcpyAsync(&n_out, keep_scan + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         *out_count = (int64_t)n_out;
         if (!on_dev && n_out) {
             HIP_TRY(hipMemcpyAsync(out_v, d_out_v, (size_t)n_out * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
             if (has_attr) HIP_TRY(hipMemcpyAsync(out_a, d_out_a, (size_t)n_out * cols * sizeof(A), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
         }
     } while (0);
     ctx_end(c);
@@ -203,13 +203,13 @@ static int dedup_impl(pcu_hip_ctx* c, const T* pts, int64_t n, double epsilon, T
         HIP_TRY(hipGetLastError());
         unsigned n_out = 0;
         HIP_TRY(hipMemcpyAsync(&n_out, scan + (n - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         *out_count = (int64_t)n_out;
         if (!on_dev) {
             HIP_TRY(hipMemcpyAsync(out_pts, d_out, (size_t)n_out * 3 * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_svi, d_svi, (size_t)n_out * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_svj, d_svj, N * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_WAIT(s);
         }
     } while (0);
     ctx_end(c);
@@ -240,7 +240,7 @@ static int pairwise_impl(pcu_hip_ctx* c, const T* a, const T* b, int64_t nb, int
         hipLaunchKernelGGL((k_pairwise<T>), dim3((unsigned)pw_blocks, (unsigned)nb), dim3(256), 0, s, da, db, (int)m, (int)n, (int)d, pc, p_norm, dout, (int)pw_cols);
         HIP_TRY(hipGetLastError());
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out, dout, no * sizeof(T), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
     } while (0);
     ctx_end(c);
     return rc ? (rc < 0 ? rc : PCU_HIP_ERR_RUNTIME) : 0;
@@ -301,7 +301,7 @@ static int sinkhorn_impl(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int
             hipLaunchKernelGGL((k_sink_check<T>), dim3(1), dim3(1024), 0, s, k, (T)stop_thresh, flagsd + 1);
             if ((it & 7) == 7) {             // every 8 iterations: has the stopping rule fired? (later launches are no-ops once it has)
                 HIP_TRY(hipMemcpyAsync(host_flags, flagsd, sizeof host_flags, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_WAIT(s);
                 if (host_flags[0]) break;
             }
         }
@@ -312,7 +312,7 @@ static int sinkhorn_impl(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host_flags, flagsd, sizeof host_flags, hipMemcpyDeviceToHost, s));
         if (!on_dev) HIP_TRY(hipMemcpyAsync(out_P, dP, nM * sizeof(T), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         if (out_iters) *out_iters = host_flags[1];
     } while (0);
     ctx_end(c);
@@ -336,7 +336,7 @@ static int dot_impl(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, doubl
         HIP_TRY(hipGetLastError());
         double h[kParts];
         HIP_TRY(hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_WAIT(s);
         double r = 0; for (int i = 0; i < kParts; ++i) r += h[i];
         *out = r;
     } while (0);

@@ -9,10 +9,12 @@
 #   gpurun_out/<tag>_configs.jsonl              one bench.py --config line per config (parity checked inside the line)
 # then `python profiles/postprocess.py <tag>` (CPU side) turns them into the tracked summaries under profiles/.
 # Counter passes never carry trace domains other than --kernel-trace (gpurun refuses --pmc with sys/hip/hsa traces).
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
+# the commit of this snapshot (written by the caller before gpurun: `git describe --always --dirty > profiles/.collect_commit`; no .git on the box)
+cp $ROOT/profiles/.collect_commit $OUT/${TAG}_commit.txt 2>/dev/null || echo unknown > $OUT/${TAG}_commit.txt
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
 # (PCU_COLLECT_LINES / PCU_COLLECT_CONFIGS: subsets of the config lists below, for a quick check of the pipeline)

@@ -4,8 +4,14 @@
    profiles/hbm_traffic.json (read by bench.py: measured HBM bytes per launch + issue-side fractions of the dominant kernel)."""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
+# the commit the collection ran at: profiles/.collect_commit is written next to the gpurun call (the GPU box has no .git) and travels with the snapshot;
+# collect.sh copies it into the output directory
+try:
+    COMMIT = open(os.path.join(G, f"{tag}_commit.txt")).read().strip()
+except OSError:
+    COMMIT = None
 N_SIMD, N_CU = 1024, 256          # MI355X: 256 CUs x 4 SIMD-32
 line = [l for l in open(os.path.join(G, f"{tag}_bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
@@ -69,7 +75,7 @@ for k in fetch:
 open(os.path.join(P, f"{tag}_pmc.txt"), "w").write("\n".join(out) + "\n")
 
 dom = [k for k in traffic if k.startswith("k_search1_flat<float")]
-rep = {"source": f"profiles/{tag}_pmc.txt", "counters_source": f"profiles/{tag}_pmc.txt + profiles/{tag}_calib.txt",
+rep = {"commit": COMMIT, "source": f"profiles/{tag}_pmc.txt", "counters_source": f"profiles/{tag}_pmc.txt + profiles/{tag}_calib.txt",
        "k_search1_flat_f32_bytes_per_launch": traffic[dom[0]] if dom else None,
        "index_build_bytes_per_step": sum(v for k, v in traffic.items() if k.startswith(("k_bbox", "k_make_grid", "k_bucket"))),      # every pass is one launch for both clouds
        "note": "one launch = both directions of the 1M-vs-1M Chamfer step; calibrated FETCH_SIZE + WRITE_SIZE, see the header of the source file"}
@@ -123,7 +129,7 @@ for c_ in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier"):
                  "hbm_bytes_per_launch": f * 1024 * (f_gather if gather else f_stream) + w * 1024 * w_stream if (f or w) else None}
     if not ks: continue
     dom_c = max(ks, key=lambda k: ks[k]["total_us"])
-    cfgk[c_] = {"dominant": dom_c, "dominant_avg_us": ks[dom_c]["avg_us"], "dominant_launches_per_call": ks[dom_c]["launches_per_call"],
+    cfgk[c_] = {"commit": COMMIT, "dominant": dom_c, "dominant_avg_us": ks[dom_c]["avg_us"], "dominant_launches_per_call": ks[dom_c]["launches_per_call"],
                 "dominant_hbm_bytes_per_launch": ks[dom_c]["hbm_bytes_per_launch"],
                 "gpu_us_per_call": sum(v["total_us"] for v in ks.values()) / n_calls,
                 "hbm_bytes_per_call": sum((v["hbm_bytes_per_launch"] or 0) * v["launches_per_call"] for v in ks.values()),

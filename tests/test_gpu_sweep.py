@@ -1,0 +1,166 @@
+"""Randomised parity sweep inside the driver-run suite (-m gpu): the HIP path through the C ABI against the reference's own nanoflann
+(oracle/_ref; the C restatement where that is not built) on cases drawn fresh every round.
+
+Round 4's review: the 2 100-case sweeps lived in scratch/fuzz.py (builder-run), 14 cases in the suite, and each round's sweep found holes in
+that round's kernels. This file moves the volume in front of the driver:
+  * 160 cases of the general sweep (ten point distributions x sizes 1 .. 60k x f32 / f64 x k in {1, 1, 1, 2, 5, 16}); every operator per case;
+  * the moderate-offset family: a query cloud 3, 10, 30, 100 box sizes away from its dataset (d2 gaps of tens of ulps between neighbours;
+    before, only offset 1000 and one offset-3 case were covered), f32 and f64, k in {1, 16};
+  * lane-pass near ties: dataset point pairs constructed to lie 1 .. 8 ulps apart in d2 from grid-interior queries, the regime in which a
+    minimum-taking search and nanoflann's incremental bound could disagree (DESIGN 2 "Near ties").
+Seeds derive from ROUND (bump it per round: new cases each round) or PCU_SWEEP_SEED. Sizes are chosen so that the whole file runs in about two
+minutes, the CPU reference included; every GPU call also carries a generous time bound (a pathological path is a finding too)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROUND = 5
+SEED = int(os.environ.get("PCU_SWEEP_SEED", 1000 * ROUND + 7))
+N_GENERAL = 160
+DISTS = ["uniform", "plane", "line", "clusters", "dups", "lattice", "offset", "aniso", "sphere", "mixed"]
+
+
+@pytest.fixture(scope="module")
+def pcu():
+    import point_cloud_utils_amd as m
+    from point_cloud_utils_amd import _lib
+    assert _lib.device_count() > 0, "no GPU visible: the gfx950 path has no CPU fallback"
+    return m
+
+
+def make(rng, n, dist, dtype):
+    if dist == "uniform": a = rng.random((n, 3))
+    elif dist == "plane": a = rng.random((n, 3)); a[:, 2] = 0.25
+    elif dist == "line": a = np.zeros((n, 3)); a[:, 0] = rng.random(n)
+    elif dist == "clusters": c = rng.random((8, 3)); a = c[rng.integers(0, 8, n)] + rng.normal(0, 0.003, (n, 3))
+    elif dist == "dups": b = rng.random((max(n // 3, 1), 3)); a = b[rng.integers(0, b.shape[0], n)]
+    elif dist == "lattice": a = rng.integers(0, 12, (n, 3)).astype(np.float64)
+    elif dist == "offset": a = rng.random((n, 3)) * 1e-3 + 1000.0
+    elif dist == "aniso": a = rng.random((n, 3)) * [1000.0, 1.0, 0.001]
+    elif dist == "sphere": v = rng.normal(size=(n, 3)); a = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+    else: a = np.concatenate([rng.random((n - n // 4, 3)), rng.normal(0.5, 0.001, (n // 4, 3))])
+    return np.ascontiguousarray(a.astype(dtype))
+
+
+def check_all_operators(pcu, kind, q, r, k, tag, bound_s=5.0):
+    """k_nearest_neighbors (indices + distance bits); for k == 1 also Hausdorff (tuple), Chamfer with indices (both arrays) and the two fused
+    calls (no indices asked for) -- everything the reference would return for this pair."""
+    tol = 1e-4 if q.dtype == np.float32 else 1e-6
+    t0 = time.perf_counter()
+    d, c = pcu.k_nearest_neighbors(q, r, k)
+    assert time.perf_counter() - t0 < bound_s, (tag, "slow k_nearest_neighbors", pcu.last_stats())
+    d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
+    assert np.array_equal(c, c0), (tag, pcu.last_stats())
+    assert np.array_equal(np.asarray(d).view(np.uint8), np.asarray(d0).view(np.uint8)), tag
+    if k != 1:
+        return
+    t0 = time.perf_counter()
+    h = pcu.hausdorff_distance(q, r, return_index=True)
+    ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True)
+    ch_f, h_f = pcu.chamfer_distance(q, r), pcu.hausdorff_distance(q, r)
+    assert time.perf_counter() - t0 < 4 * bound_s, (tag, "slow metric", pcu.last_stats())
+    h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
+    ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=kind)
+    assert h == h0, (tag, h, h0)
+    assert np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0), tag
+    assert abs(float(ch) - float(ch0)) <= tol * abs(float(ch0)) + 1e-30, tag
+    assert abs(float(ch_f) - float(ch0)) <= tol * abs(float(ch0)) + 1e-30 and h_f == h0[0], (tag, ch_f, ch0, h_f, h0)
+
+
+@pytest.mark.parametrize("case", range(N_GENERAL))
+def test_general_sweep(pcu, oracle_kind, case):
+    rng = np.random.default_rng([SEED, case])
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    hi = 60000 if rng.random() < 0.5 else 3000
+    n, m = int(rng.integers(1, hi)), int(rng.integers(1, hi))
+    k = min(int(rng.choice([1, 1, 1, 2, 5, 16])), m)
+    dq, dr = str(rng.choice(DISTS)), str(rng.choice(DISTS))
+    q, r = make(rng, n, dq, dtype), make(rng, m, dr, dtype)
+    check_all_operators(pcu, oracle_kind, q, r, k, f"seed {SEED} case {case}: {dtype.__name__} n={n} m={m} k={k} q={dq} r={dr}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("k", [1, 16])
+@pytest.mark.parametrize("boxes", [3, 10, 30, 100])
+def test_moderate_offset(pcu, oracle_kind, dtype, k, boxes):
+    """The query cloud sits `boxes` dataset-box sizes away from the dataset along a random direction: no query finds its neighbours in the 27
+    cells, every one goes through the wave-per-query rounds, and the gaps between candidate d2 shrink to tens of ulps (float32) as the offset
+    grows -- the regime between the grid-interior case and the offset-1000 fixtures of round 4."""
+    rng = np.random.default_rng([SEED, 7001, boxes, k, dtype().itemsize])
+    n, m = int(rng.integers(8000, 40000)), int(rng.integers(8000, 40000))
+    u = rng.normal(size=3); u /= np.linalg.norm(u)
+    r = rng.random((m, 3)).astype(dtype)
+    q = np.ascontiguousarray((rng.random((n, 3)) * rng.choice([0.05, 1.0]) + boxes * u).astype(dtype))
+    check_all_operators(pcu, oracle_kind, q, r, k, f"offset {boxes} boxes, {dtype.__name__}, k={k}, n={n}, m={m}", bound_s=10.0)
+    check_all_operators(pcu, oracle_kind, r[: n // 2], q, k, f"offset {boxes} boxes (roles swapped), {dtype.__name__}, k={k}", bound_s=10.0)
+
+
+def near_tie_pairs(rng, dtype, nq, m_background):
+    """Queries in the interior of a uniform dataset, each given two extra dataset points r1, r2 that are its two nearest neighbours with
+    computed squared distances 1 .. 8 ulps apart (in the reference's own operation order and type). Queries and the (y, z) offsets of the
+    pair lie on a binary lattice coarse enough for every difference, square and sum to be exact: r1 = q + (0, a, b), r2 = q + (delta, -a, -b)
+    would tie exactly for delta = 0, and delta = sqrt(t ulp(d2)) lifts r2 by t ulps (the construction is checked in the input type below).
+    Returns (queries, dataset, number of constructed pairs)."""
+    T = dtype
+    L = 2.0 ** (12 if T == np.float32 else 24)
+    q = (np.floor((0.2 + 0.6 * rng.random((nq, 3))) * L) / L).astype(T)
+    bg = rng.random((m_background, 3)).astype(T)
+    steps = max(2, int(0.05 * m_background ** (-1.0 / 3.0) * L))        # the pair sits well inside the background's spacing
+    a = (rng.integers(1, steps + 1, nq) * rng.choice([-1, 1], nq) / L).astype(T)
+    b = (rng.integers(0, steps + 1, nq) * rng.choice([-1, 1], nq) / L).astype(T)
+    def d2(u, v):
+        dx, dy, dz = u[:, 0] - v[:, 0], u[:, 1] - v[:, 1], u[:, 2] - v[:, 2]
+        return ((dx * dx) + (dy * dy)) + (dz * dz)
+    r1 = np.stack([q[:, 0], q[:, 1] + a, q[:, 2] + b], 1).astype(T)
+    d1 = d2(q, r1)
+    t = rng.integers(1, 9, nq)
+    delta = np.sqrt(t * np.spacing(d1).astype(np.float64)) * rng.choice([-1, 1], nq)
+    swap = rng.random(nq) < 0.5                                          # r2's (y, z) offsets: (-a, -b) or (-b, -a)
+    oy, oz = np.where(swap, -b, -a).astype(T), np.where(swap, -a, -b).astype(T)
+    r2 = np.stack([(q[:, 0] + delta.astype(T)).astype(T), q[:, 1] + oy, q[:, 2] + oz], 1).astype(T)
+    gap = (d2(q, r2) - d1) / np.spacing(d1)
+    sel = np.nonzero((gap >= 1) & (gap <= 8))[0]
+    data = np.concatenate([bg, r1[sel], r2[sel]]).astype(T)
+    data = np.ascontiguousarray(data[rng.permutation(len(data))])        # (row order decides nothing here; mixed in for good measure)
+    return np.ascontiguousarray(q[sel]), data, len(sel)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("rep", range(4))
+def test_lane_pass_near_ties(pcu, oracle_kind, dtype, rep):
+    """Queries that the lane-per-query pass certifies, whose two best candidates are 1 .. 8 ulps apart in d2: the GPU must return what the
+    reference returns (k = 1: the lane pass; k = 2: the pair in the reference's order; the fused metrics through the same queries)."""
+    rng = np.random.default_rng([SEED, 9001, rep, dtype().itemsize])
+    q, data, npairs = near_tie_pairs(rng, dtype, 20000, 60000)
+    assert npairs > 10000, npairs                     # the construction works for most queries
+    # the constructed pairs really are the two nearest, 1 .. 8 ulps apart, for nearly all of the queries (a background point may intrude)
+    d0, c0 = oracle.k_nearest_neighbors(q, data, 2, kind=oracle_kind, squared_distances=True)
+    gap = (d0[:, 1] - d0[:, 0]) / np.spacing(d0[:, 0])
+    assert ((gap >= 1) & (gap <= 8)).mean() > 0.9
+    for k in (1, 2):
+        check_all_operators(pcu, oracle_kind, q, data, k, f"near ties rep {rep} {dtype.__name__} k={k}")
+    # many more queries than a straggler pass would take: they are answered by the lane-per-query kernels
+    st = pcu.last_stats()
+    assert st.get("n_unresolved", 0) + st.get("n_escalated", 0) < len(q) // 10, st
+
+
+@pytest.mark.parametrize("nt", [-1, 0, 4])
+def test_num_threads_is_accepted(pcu, oracle_kind, nt):
+    """a11 (src/common/common.h:182-212 OmpSetParallelism, src/point_cloud_distance.cpp:129): `num_threads` is the reference's OpenMP knob --
+    -1 all cores, 0 serial, n threads; results do not depend on it there, and here it is accepted (positionally and by keyword) and ignored."""
+    rng = np.random.default_rng([SEED, 11, nt + 1])
+    q, r = rng.random((120_000, 3)).astype(np.float32), rng.random((110_000, 3)).astype(np.float32)      # (>= 100 000 rows: where the reference's team engages)
+    d0, c0 = oracle.k_nearest_neighbors(q, r, 3, kind=oracle_kind)
+    d, c = pcu.k_nearest_neighbors(q, r, 3, num_threads=nt)
+    assert np.array_equal(c, c0) and np.array_equal(d, d0)
+    d, c = pcu.k_nearest_neighbors(q, r, 3, False, 10, nt)
+    assert np.array_equal(c, c0) and np.array_equal(d, d0)
+    d1, c1 = pcu.k_nearest_neighbors(q[:500], r[:700], 1, squared_distances=True, max_points_per_leaf=7, num_threads=nt)
+    e1, f1 = oracle.k_nearest_neighbors(q[:500], r[:700], 1, squared_distances=True, max_points_per_leaf=7, kind=oracle_kind)
+    assert np.array_equal(c1, f1) and np.array_equal(d1, e1)
