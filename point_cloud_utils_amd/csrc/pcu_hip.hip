@@ -308,7 +308,8 @@ static int max_cells_for(int64_t n, double occ) {
 // which it grows with n like everything else; index_bytes() counts exactly what index_alloc() takes.
 static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     static const bool off = [] { const char* e = getenv("PCU_HIP_INDEX"); return e && strcmp(e, "atomic") == 0; }();
-    if (off || n < 32768 || occ > 64.0) return false;
+    static const int64_t n_min = getenv("PCU_HIP_BUCKET_MIN") ? atoll(getenv("PCU_HIP_BUCKET_MIN")) : 2048;       // below: the atomic build (round 4: 32768; see wave_only_below)
+    if (off || n < n_min || occ > 64.0) return false;
     const int mc = max_cells_for(n, occ);
     int sh = 5;
     while (sh < 12 && (double)(2 << sh) * occ <= (double)kBucketPts) ++sh;             // largest bucket with <= ~kBucketPts expected points
@@ -579,7 +580,13 @@ static double default_occupancy(int k) {
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 constexpr int kMaxKLane = 32;       // lane-per-query register slots (K = 64 needs 203-275 VGPRs: those k go wave-per-query from the start)
 constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
-constexpr int kWaveOnlyBelow = 16384;   // fewer queries than this: wave-per-query from the start
+// Fewer queries than this: wave-per-query from the start (PCU_HIP_WAVE_ONLY_BELOW overrides). Round 5: 16384 -> 2048, together with the one-pass
+// index build from 2048 points on (bucket_plan): a 10k-vs-10k call is then the same four launches as a 1M-vs-1M one (build x 2, lane pass, tail)
+// instead of thirteen (bbox, grid, 4 atomic-build passes per cloud, two wave-per-query launches, epilogue): config 1 0.159 -> 0.056 ms, the
+// 2 885-query direction of config 5 0.246 -> 0.201 ms (profiles/r05_small_ab.txt). 40 blocks of a lane pass do not fill the GPU -- a launch's
+// latency chain does not care.
+static int wave_only_below() { static const int v = getenv("PCU_HIP_WAVE_ONLY_BELOW") ? atoi(getenv("PCU_HIP_WAVE_ONLY_BELOW")) : 2048; return v; }
+#define kWaveOnlyBelow wave_only_below()
 constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
                                         // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)
 // Occupancy rescale. The default occupancy is right for clouds that fill their bounding box. A cloud sampled from a surface puts
@@ -635,6 +642,18 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     }
     if (a1) return fail(PCU_HIP_ERR_RUNTIME, "internal: paired main pass without the k = 1 kernel");
     dim3 grid(grid8(nwork, tb)), block(tb);
+    // k > 1 on an open index: the run-list kernel (search.h: k_search_runs, round 5); PCU_HIP_KSEARCH_V1=1 keeps k_search everywhere (A/B, switch test)
+    static const bool runs_off = getenv("PCU_HIP_KSEARCH_V1") != nullptr;
+    if (K > 1 && open_index && !runs_off) {
+#define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_runs<T, KK>), grid, block, 0, s, a); break;
+        switch (K) {
+            case 2: PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32)
+            default: return fail(PCU_HIP_ERR_INVALID, "internal: unsupported K=%d", K);
+        }
+#undef PCU_CASE
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search<T, KK>), grid, block, 0, s, a); break;
     switch (K) {
         PCU_CASE(1) case 2: PCU_CASE(4) PCU_CASE(8) PCU_CASE(16) PCU_CASE(32)      // (k = 2 keeps a list of 4: one instantiation pair less, 0.2 MB)

@@ -938,6 +938,190 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     f_v = a.squared ? best : sqrt(best);
     f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
 }
+// -------------------------------------------------------------------------------------------------------
+// Main pass for k > 1 on an OPEN index (round 5): k_search's scan on the k = 1 kernel's plan. k_search walks the nine rows one after the
+// other, every row as long as its longest lane (44 % active lanes at 4M-vs-4M, k = 16: profiles/r04_c3_pmc.txt) and with no cell cuts. Here
+//   * the row tables come from the per-axis terms the k = 1 kernel shares between its rows (uniform four-word tables, see search1_flat_body);
+//   * the centre row is scanned whole and its candidates inserted, which gives a first k-th best (the default occupancy for k > 1 puts
+//     ~3 k / 2 points into those three cells);
+//   * the outer cells of the other eight rows are cut against that k-th best, the surviving runs go to the lane's list in LDS, and ONE
+//     software-pipelined loop consumes the list -- a wave runs max-over-lanes of the TOTAL group count; a run is dropped when its row bound
+//     has been overtaken by the k-th best by the time the lane reaches it.
+// Candidates are still the 16 / 32-byte Pt4 records (a candidate that is accepted needs its row id at once), slots past a run's end read the
+// +inf sentinel record (a record offered twice would sit twice in the list), accepted candidates are parked and inserted in bursts exactly
+// as in k_search: same offers, same tie flags, same certification (finish_lane). Closed sub-box levels keep k_search.
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
+    static_assert(K > 1, "k = 1 has k_search1_flat");
+    const int per = (int)(gridDim.x >> 3);
+    const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // XCD-aware block order, see k_search
+    const int tid = threadIdx.x;
+    const int t = vb * kBlock + tid;
+    const int nq = a.qcount_dev ? *a.qcount_dev : a.nq;
+    const GridParams<T>& g = *a.gp;
+    if (t >= nq) return;
+    const int qpos = a.qlist ? a.qlist[t] : t;
+    const Pt4<T> q = a.qsorted[qpos];
+    if (const int hl = index_not_ready(a, g)) { if (t == 0) a.skew_flag[kLargeFlag] = hl; return; }
+    if (a.skew_limit > 0.f && ((float)g.sumsq > a.skew_limit || (float)g.sumsq < a.skew_lo)) { if (t == 0) *a.skew_flag = (float)g.sumsq > a.skew_far ? 2 : 1; return; }
+    const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+    const int ccx = cell_of_query(g, 0, q.x), ccy = cell_of_query(g, 1, q.y), ccz = cell_of_query(g, 2, q.z);
+
+    T bd[K]; int bi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { bd[i] = Limits<T>::max_v; bi[i] = 0x7fffffff; }
+    bool tie = false;
+    constexpr int kBuf = PCU_KBUF;
+    constexpr int kGroup = 4;
+    __shared__ T s_bd[kBuf][kBlock];
+    __shared__ int s_bi[kBuf][kBlock];
+    __shared__ uint2 s_rng[8][kBlock];
+    int cnt = 0;
+    auto flush = [&]() {
+        int mx = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        for (int i = 0; i < mx; ++i)
+            if (i < cnt) offer<T, K>(s_bd[i][tid], s_bi[i][tid], bd, bi, tie);
+        cnt = 0;
+    };
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const unsigned sentinel = a.n_ref;
+    // four records from record p on, slots at or past record e replaced by the sentinel
+    auto load_group = [&](unsigned p, unsigned e, Pt4<T> (&c)[kGroup]) {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) {
+            const unsigned idx = (p + u < e) ? p + u : sentinel;
+            c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
+        }
+    };
+    auto eval_group = [&](const Pt4<T> (&c)[kGroup]) {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) {
+            const T d = dist2(q, c[u]);
+            tie = tie || (d == bd[K - 1]);            // as offer() would flag it (the k-th best may be stale: conservative)
+            if (d < bd[K - 1]) { s_bd[cnt][tid] = d; s_bi[cnt][tid] = (int)c[u].idx; ++cnt; }
+        }
+        if (__any(cnt > kBuf - kGroup)) flush();
+    };
+
+    // ---- row tables (search1_flat_body)
+    const bool hasxl = ccx > 0, hasxh = ccx < Gx - 1;
+    const bool odd0 = ((ccy ^ ccz) & 1) != 0, zodd = (ccz & 1) != 0;
+    const bool hasA = (odd0 && hasxh) || (!odd0 && hasxl), hasB = (odd0 && hasxl) || (!odd0 && hasxh);
+    const unsigned Gx4 = (unsigned)Gx << 2;
+    const unsigned xe4 = (unsigned)ccx << 2, xo4 = (unsigned)(Gx - 1 - ccx) << 2;
+    const unsigned xS4 = odd0 ? xo4 : xe4, xR4 = odd0 ? xe4 : xo4;
+    const int yS = zodd ? Gy - 1 - ccy : ccy, sS = zodd ? -1 : 1;
+    const int row0 = (int)mad24((unsigned)ccz, (unsigned)Gy, (unsigned)yS);
+    const int flip = (Gy - 1 - yS) - yS;
+    const int rowM = row0 + flip - Gy, rowP = row0 + flip + Gy;
+    const bool okyM = ccy > 0, okyP = ccy < Gy - 1, okzM = ccz > 0, okzP = ccz < Gz - 1;
+    const char* const tbase = reinterpret_cast<const char*>(a.cell_start) - 4;
+    bool okj[9];
+    CellStart4 tb[9];
+    auto row_table = [&](int j) {
+        const int oy = kRowOy[j], oz = kRowOz[j];
+        okj[j] = (oy == 0 || (oy < 0 ? okyM : okyP)) && (oz == 0 || (oz < 0 ? okzM : okzP));
+        const int rr = oz == 0 ? row0 + oy * sS : (oz < 0 ? rowM : rowP) - oy * sS;
+        const unsigned row = (unsigned)(okj[j] ? rr : row0);
+        tb[j] = *reinterpret_cast<const CellStart4*>(tbase + (size_t)(__umul24(row, Gx4) + (((oy + oz) & 1) == 0 ? xS4 : xR4)));
+    };
+    row_table(0);                                     // (the other eight after the centre scan: 32 registers less while it runs)
+    // ---- centre row: whole run, pipelined
+    const unsigned c_s = hasA ? tb[0].v[0] : tb[0].v[1], c_e = hasB ? tb[0].v[3] : tb[0].v[2];
+    const unsigned cnt0 = c_e - c_s;
+    const unsigned cand_cap = a.lane_max_cand < 65535u ? a.lane_max_cand : 65535u;     // a run's record count is packed into 16 bits
+    bool defer = cnt0 > cand_cap;
+    if (!defer && cnt0 > 0u) {
+        unsigned p = c_s;
+        Pt4<T> ca[kGroup], cb[kGroup];
+        load_group(p, c_e, ca);
+        for (;;) {
+            p += kGroup;
+            load_group(p, c_e, cb);                  // (past the end: four sentinel records, evaluated to +inf and never parked)
+            eval_group(ca);
+            if (!(p < c_e)) break;
+            p += kGroup;
+            load_group(p, c_e, ca);
+            eval_group(cb);
+            if (!(p < c_e)) break;
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < 9; ++j) row_table(j);
+    if (__any(cnt > 0)) flush();                      // the cuts below want the k-th best of everything seen so far (the tables' latency is behind it)
+    // ---- bounds, cuts, run list
+    const T shrink = (T)1 - (T)4 * Limits<T>::eps;
+    T mxl = q.x - face_below(g, 0, ccx); mxl = mxl > (T)0 ? mxl * shrink : (T)0;
+    T mxh = face_above(g, 0, ccx) - q.x; mxh = mxh > (T)0 ? mxh * shrink : (T)0;
+    const T mxl2 = mxl * mxl, mxh2 = mxh * mxh;
+    const T mA2 = odd0 ? mxh2 : mxl2, mB2 = odd0 ? mxl2 : mxh2;
+    T my2[3], mz2[3];
+    {
+        T m;
+        my2[0] = (T)0; mz2[0] = (T)0;
+        m = q.y - face_below(g, 1, ccy); m = m > (T)0 ? m * shrink : (T)0; my2[1] = m * m;
+        m = face_above(g, 1, ccy) - q.y; m = m > (T)0 ? m * shrink : (T)0; my2[2] = m * m;
+        m = q.z - face_below(g, 2, ccz); m = m > (T)0 ? m * shrink : (T)0; mz2[1] = m * m;
+        m = face_above(g, 2, ccz) - q.z; m = m > (T)0 ? m * shrink : (T)0; mz2[2] = m * m;
+    }
+    unsigned total = cnt0;
+    int n = 0;
+    {
+        const T kth = bd[K - 1];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) {
+            const int oy = kRowOy[j], oz = kRowOz[j];
+            const T ry = my2[oy == 0 ? 0 : (oy < 0 ? 1 : 2)], rz = mz2[oz == 0 ? 0 : (oz < 0 ? 1 : 2)];
+            const bool same = ((oy + oz) & 1) == 0;
+            const T mF2 = same ? mA2 : mB2, mL2 = same ? mB2 : mA2;
+            const bool hasF = same ? hasA : hasB, hasL = same ? hasB : hasA;
+            const T rlb = oy == 0 ? rz : (oz == 0 ? ry : ry + rz);
+            const T bF = oy == 0 ? mF2 + rz : (oz == 0 ? mF2 + ry : (mF2 + ry) + rz), bL = oy == 0 ? mL2 + rz : (oz == 0 ? mL2 + ry : (mL2 + ry) + rz);
+            const bool cutF = !hasF || kth < bF, cutL = !hasL || kth < bL;          // (strict: a tie at the k-th slot is not cut away)
+            const unsigned s_run = cutF ? tb[j].v[1] : tb[j].v[0], e_run = cutL ? tb[j].v[2] : tb[j].v[3];
+            const bool take = okj[j] && !defer && !(kth < rlb) && e_run > s_run;
+            s_rng[n][tid] = make_uint2(s_run, ((e_run - s_run) << 16) | lb_pack(rlb));
+            n += take ? 1 : 0;
+            total += take ? e_run - s_run : 0u;
+        }
+    }
+    if (total > cand_cap) { defer = true; n = 0; cnt = 0; }
+    // ---- one loop over the listed runs
+    int r = 0;
+    unsigned p = 0, end = 0;
+    bool live = false;
+    auto next_run = [&]() {
+        live = false;
+        while (r < n) {
+            const uint2 e = s_rng[r][tid];
+            ++r;
+            if (!(bd[K - 1] < lb_unpack<T>(e.y & 0xffffu))) { p = e.x; end = e.x + (e.y >> 16); live = true; break; }
+        }
+    };
+    next_run();
+    if (live) {
+        Pt4<T> ga[kGroup], gb[kGroup];
+        load_group(p, end, ga);
+        for (;;) {
+            p += kGroup;
+            if (p >= end) next_run();
+            load_group(live ? p : sentinel, live ? end : sentinel, gb);
+            eval_group(ga);
+            if (!live) break;
+            p += kGroup;
+            if (p >= end) next_run();
+            load_group(live ? p : sentinel, live ? end : sentinel, ga);
+            eval_group(gb);
+            if (!live) break;
+        }
+    }
+    if (__any(cnt > 0)) flush();
+    finish_lane<T, K>(a, g, q, qpos, max(ccx - 1, 0), min(ccx + 1, Gx - 1), max(ccy - 1, 0), min(ccy + 1, Gy - 1), max(ccz - 1, 0), min(ccz + 1, Gz - 1),
+                      bd, bi, tie, true, defer);
+}
+
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
 template <typename T> struct SearchArgs2 { SearchArgs<T> a[2]; };
 template <typename T, bool EARLY, int MINW, int FUSE>

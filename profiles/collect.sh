@@ -51,4 +51,10 @@ for c in ${PCU_COLLECT_CONFIGS:-c1 c2 c3 c4 c5 gauss cluster outlier}; do
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_fetch -- $CB > $OUT/${TAG}_${c}_pmc_fetch.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${c}_pmc_write -- $CB > $OUT/${TAG}_${c}_pmc_write.log 2>&1
 done
+# the widened rows: kernel trace only
+for c in ${PCU_COLLECT_FROWS:-normals voxel sinkhorn morton}; do
+  CB="python $ROOT/bench.py --config $c --steps 4 --warmup 2 --no-parity --no-kernel-events"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${c}_trace -- $CB > $OUT/${TAG}_${c}_trace.log 2>&1
+  summarise ${TAG}_${c}_trace
+done
 cut -c1-260 $OUT/${TAG}_configs.jsonl

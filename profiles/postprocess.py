@@ -144,6 +144,13 @@ for c_ in ("c1", "c2", "c3", "c4", "c5", "gauss", "cluster", "outlier"):
         lines_c.append(f"{k:44s} launches/call {v['launches_per_call']:6.2f} avg_us {v['avg_us']:9.2f} FETCH_SIZE={f:11.1f} WRITE_SIZE={w:11.1f} hbm_bytes/launch={(hb if hb is not None else float('nan')):.4g}")
     open(os.path.join(P, f"{tag}_{c_}_pmc.txt"), "w").write("\n".join(lines_c) + "\n")
 json.dump(cfgk, open(os.path.join(P, "config_kernels.json"), "w"), indent=1)
+# ---- the widened rows: kernel statistics only
+for c_ in ("normals", "voxel", "sinkhorn", "morton"):
+    sm = os.path.join(G, f"{tag}_{c_}_trace_summary.txt")
+    if os.path.exists(sm):
+        txt_c = open(sm).read().split("\n\n")[0].replace("/root/repo/", "").replace(ROOT + "/", "")
+        open(os.path.join(P, f"{tag}_{c_}_kernel_stats.txt"), "w").write(
+            f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {c_} --steps 4 --warmup 2 --no-parity --no-kernel-events (7 calls of the operator; commit {COMMIT})\n" + txt_c + "\n")
 cfg = os.path.join(G, f"{tag}_configs.jsonl")
 if os.path.exists(cfg):
     open(os.path.join(P, f"{tag}_configs.jsonl"), "w").write(open(cfg).read())

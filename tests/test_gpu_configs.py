@@ -159,7 +159,10 @@ SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINU
             # fused calls, level passes all the way down / one workgroup for the whole tie-order tree, refits one direction at a time
             "PCU_HIP_BUILD_V1=1", "PCU_HIP_NO_LEAN=1", "PCU_HIP_ROW_OUT_MIN_K=4", "PCU_HIP_FUSED_WAVE=1", "PCU_HIP_KD_FINISH_MAX=0",
             "PCU_HIP_KD_FINISH_MAX=1000000000", "PCU_HIP_NO_SKEW_OVERLAP=1", "PCU_HIP_SPEC_PRIORITY=1", "PCU_HIP_PROF_BUILD2=1",
-            "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255", "PCU_HIP_NO_WAVE_MERGE=1"]
+            "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255", "PCU_HIP_NO_WAVE_MERGE=1",
+            # round 5: k > 1 lane pass without the run list (k_search everywhere), the round-4 small-cloud thresholds (wave-per-query below
+            # 16384 queries, atomic build below 32768 points), no SIGINT watch
+            "PCU_HIP_KSEARCH_V1=1", "PCU_HIP_WAVE_ONLY_BELOW=16384", "PCU_HIP_BUCKET_MIN=32768", "PCU_HIP_NO_SIGINT=1"]
 
 
 @pytest.mark.gpu
