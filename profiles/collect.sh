@@ -16,12 +16,12 @@ mkdir -p $OUT
 # the commit of this snapshot (written by the caller before gpurun: `git describe --always --dirty > profiles/.collect_commit`; no .git on the box)
 cp $ROOT/profiles/.collect_commit $OUT/${TAG}_commit.txt 2>/dev/null || echo unknown > $OUT/${TAG}_commit.txt
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-configs"
 # (PCU_COLLECT_LINES / PCU_COLLECT_CONFIGS: subsets of the config lists below, for a quick check of the pipeline)
 python $ROOT/bench.py --steps 50 --warmup 5 ${PCU_COLLECT_BENCH_FLAGS:-} > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # (a rocprofv3 database is ~14 MB and gpurun brings back 64 MiB at most: every trace is summarised here and its database dropped)
 summarise() { db=$(find $OUT/$1 -name "*results.db" | head -1); python $ROOT/profiles/summarize_rocprof.py $db --json $OUT/$1_kernels.json > $OUT/$1_summary.txt 2>/dev/null; rm -rf $OUT/$1; }
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity > $OUT/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-configs > $OUT/${TAG}_trace.log 2>&1
 summarise ${TAG}_trace
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
 pass fetch FETCH_SIZE

@@ -5,7 +5,7 @@ TAG=${1:-b}; shift
 for kv in "$@"; do export "$kv"; done
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity ${PCU_BENCH_ARGS:-}"
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-configs ${PCU_BENCH_ARGS:-}"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -- $B > $OUT/${TAG}_pmc_$c.log 2>&1
 done

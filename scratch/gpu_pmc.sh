@@ -6,7 +6,7 @@ for e in "$@"; do export "$e"; done
 python -c "import torch"
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-configs"
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE
 pass sq2 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE

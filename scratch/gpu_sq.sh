@@ -5,7 +5,7 @@ TAG=${1:-p}; PAT=${2:-k_search1}; shift; shift
 for kv in "$@"; do export "$kv"; done
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity"
+B="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-configs"
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_pmc_$name -- $B > $OUT/${TAG}_pmc_$name.log 2>&1; }
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 pass sq2 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE
