@@ -630,7 +630,10 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
         // (An LDS-staged, block-cooperative variant of this pass -- the north-star's tile design -- was measured again in round 4: 243-593 us
         // against 77 us, profiles/r04_flat_tile_ab.txt; removed.)
-#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, (sizeof(T) == 4 && FUSE == FUSE_SUM) ? 8 : 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
+#ifndef PCU_FLAT_MINW
+#define PCU_FLAT_MINW 8
+#endif
+#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, (sizeof(T) == 4 && FUSE == FUSE_SUM) ? PCU_FLAT_MINW : 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
         // (a variant that deals a wave's candidate groups evenly to its lanes -- LDS list + atomic min -- measured 75.6 vs 76.5 us: the loop is
         // not where the instructions are, profiles/r04_flat_deal_ab.txt; removed)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);

@@ -636,6 +636,10 @@ template <> struct GroupEval<double, true> {
         for (int u = 0; u < 4; ++u) { const double dx = q.x - g.v[3 * u], dy = q.y - g.v[3 * u + 1], dz = q.z - g.v[3 * u + 2]; d[u] = ((dx * dx) + (dy * dy)) + (dz * dz); }
     }
 };
+// A value's bit pattern as an unsigned integer: for d2 >= +0 the patterns order like the values (LDS atomic min on distances, see "adoption")
+template <typename T> struct BitsOf;
+template <> struct BitsOf<float> { typedef unsigned type; static __device__ __forceinline__ unsigned of(float v) { return __float_as_uint(v); } static __device__ __forceinline__ float back(unsigned b) { return __uint_as_float(b); } };
+template <> struct BitsOf<double> { typedef unsigned long long type; static __device__ __forceinline__ unsigned long long of(double v) { return (unsigned long long)__double_as_longlong(v); } static __device__ __forceinline__ double back(unsigned long long b) { return __longlong_as_double((long long)b); } };
 // Register layout: the centre row's table is loaded and scanned first; only then are the other eight rows' tables fetched
 // (EARLY = false: one more dependent wait per wave, but their 32 registers are not live during the centre scan: 68 VGPRs
 // instead of 93, 7 waves per SIMD instead of 5). EARLY = true fetches them right away (79 VGPRs; measured equal).
@@ -786,6 +790,95 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     // that has just run out of work fetches the +inf sentinel records once): loads issued under a branch would make the compiler wait
     // for them at the join, i.e. before the older group is evaluated.
     const unsigned sent_off = a.n_ref * kRec;
+#ifndef PCU_ADOPT
+#define PCU_ADOPT 1
+#endif
+#ifndef PCU_ADOPT_T
+#define PCU_ADOPT_T 3
+#endif
+    // ---- adoption (round 5, fused sum only). The loop below runs until the wave's slowest lane is done: ~10 groups for a mean need of 3.5
+    // (profiles/r05_flat_ab.txt), and every trip costs the CU's texture-address path three gather instructions whatever the number of lanes
+    // still in it -- the resource that bounds this kernel. So every lane first evaluates at most TWO groups of its own list (which keeps the
+    // adaptive row pruning where it pays: a lane's first groups tighten its minimum most); then the groups the wave's lanes still owe
+    // -- runs not yet overtaken by their lane's minimum, ~130 per wave -- are listed in LDS (slots by a wave prefix sum) and evaluated by all 64
+    // lanes in lock step, item w by lane w mod 64, against the query of the lane that listed it (coordinates through the LDS crossbar), a
+    // group's minimum merged into its owner's best by an LDS atomic min on the value's bits (d2 >= +0: the bit patterns order like the values;
+    // +inf sentinels and NaN sort behind every finite value, as with '<'). ~3 lock-step trips instead of ~8 more max-over-lanes trips; the same
+    // candidates or a few more (what the owner's shrinking minimum would have skipped), all of them dataset points of the box -- the minimum is
+    // the same. Only the fused sum needs no more than the minimum (no winner's row, no tie flags); a wave whose list would not fit, or with
+    // exited lanes, goes on lane by lane.
+    if (PCU_ADOPT && FUSE == FUSE_SUM) {
+        // (list capacity: with the run list, the block's fold and 8 blocks per CU -- the occupancy the kernel is tuned for -- 160 four-byte items
+        // per wave are what fits the 160 KB of LDS; an item = record index of the group (26 bits: clouds of 2^26 records or more go on lane by
+        // lane) | owner lane << 26. After three own groups a wave owes ~90 groups on a uniform cloud, 140 at most in the replay.)
+        constexpr int kAdoptCap = 160;
+        constexpr int kOwn = PCU_ADOPT_T;
+        typedef typename BitsOf<T>::type Bits;
+        __shared__ unsigned s_aitem[kBlock / 64][kAdoptCap];
+        __shared__ Bits s_abest[kBlock / 64][64];
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        constexpr unsigned kStep = (unsigned)kG * kRec;
+        if (live) {                                      // the lane's own first groups, the next one requested before the current one is evaluated
+            typename GE::Raw g0 = GE::load(base, off);
+#pragma unroll
+            for (int it = 0; it < kOwn; ++it) {
+                const unsigned coff = off;
+                off += kStep;
+                if (off >= end) next_run();
+                typename GE::Raw g1;
+                if (it + 1 < kOwn) g1 = GE::load(base, live ? off : sent_off);
+                PCU_K1_EVAL(g0, coff)
+                if (!live) break;
+                if (it + 1 < kOwn) g0 = g1;
+            }
+        }
+        if (__ballot(true) == ~0ull && a.n_ref < (1u << 26)) {
+            // groups this lane still owes (runs its minimum has overtaken in the meantime are dropped here as the loop would drop them)
+            unsigned c = 0;
+            if (live) {
+                c = (end - off + kStep - 1u) / kStep;
+                for (int rr = r; rr < n; ++rr) { const uint2 e = s_rng[rr][own]; if (!(best < lb_unpack<T>(e.y & 0xffffu))) c += ((e.y >> 16) + (unsigned)kG - 1u) / (unsigned)kG; }
+            }
+            unsigned inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned u = (unsigned)__shfl_up((int)inc, o, 64); if (lane_ >= o) inc += u; }
+            const unsigned W = (unsigned)__shfl((int)inc, 63, 64);
+            if (W != 0u && W <= (unsigned)kAdoptCap) {
+                unsigned slot = inc - c;
+                const unsigned tag = (unsigned)lane_ << 26;
+                if (c) {
+                    for (unsigned o = off; o < end; o += kStep) { s_aitem[wave_][slot] = (o / kRec) | tag; ++slot; }
+                    for (int rr = r; rr < n; ++rr) {
+                        const uint2 e = s_rng[rr][own];
+                        if (!(best < lb_unpack<T>(e.y & 0xffffu))) {
+                            const unsigned r0 = e.x / kRec, r1 = r0 + (e.y >> 16);
+                            for (unsigned o = r0; o < r1; o += (unsigned)kG) { s_aitem[wave_][slot] = o | tag; ++slot; }
+                        }
+                    }
+                }
+                s_abest[wave_][lane_] = BitsOf<T>::of(best);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (unsigned wb = 0; wb < W; wb += 64u) {          // (uniform trips; one register set: 8 waves per SIMD hide a trip's latency)
+                    const unsigned w_ = wb + (unsigned)lane_;
+                    const bool in_ = w_ < W;
+                    const unsigned it_ = in_ ? s_aitem[wave_][in_ ? w_ : 0u] : 0u;
+                    const int ql = in_ ? (int)(it_ >> 26) : lane_;
+                    const typename GE::Raw g1 = GE::load(base, in_ ? rec_bytes<kRec>(it_ & 0x03ffffffu) : sent_off);
+                    Pt4<T> qq; qq.x = __shfl(q.x, ql, 64); qq.y = __shfl(q.y, ql, 64); qq.z = __shfl(q.z, ql, 64); qq.idx = 0;
+                    T d_[4]; GE::dists(g1, qq, d_);
+                    const T m_ = min4(d_[0], d_[1], d_[2], d_[3]);
+                    if (in_) atomicMin(&s_abest[wave_][ql], BitsOf<T>::of(m_));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                best = BitsOf<T>::back(s_abest[wave_][lane_]);
+                live = false;
+            }
+        }
+    }
     if (live) {
         typename GE::Raw ga = GE::load(base, off), gb;
         for (;;) {
