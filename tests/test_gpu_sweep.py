@@ -164,3 +164,27 @@ def test_num_threads_is_accepted(pcu, oracle_kind, nt):
     d1, c1 = pcu.k_nearest_neighbors(q[:500], r[:700], 1, squared_distances=True, max_points_per_leaf=7, num_threads=nt)
     e1, f1 = oracle.k_nearest_neighbors(q[:500], r[:700], 1, squared_distances=True, max_points_per_leaf=7, kind=oracle_kind)
     assert np.array_equal(c1, f1) and np.array_equal(d1, e1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("dq,dr", [("uniform", "uniform"), ("uniform", "sphere"), ("clusters", "uniform"), ("mixed", "mixed"), ("plane", "uniform"),
+                                   ("dups", "uniform"), ("aniso", "aniso"), ("sphere", "sphere")])
+def test_fused_sum_is_the_sum_of_the_rows(pcu, dtype, dq, dr):
+    """The fused Chamfer sum has no rows to compare, and its value tolerance (1e-4 / 1e-6) would hide a query served a wrong neighbour. Its
+    fp64 means as the C ABI returns them (before the wrapper rounds to the input dtype) must therefore equal the fp64 sum of the k = 1 rows of
+    the same clouds to summation rounding: one wrong minimum among 10^5 queries moves a mean by >= 1e-8 relative. Exercises the lane pass of the
+    fused kernel -- centre row, cuts, run list, adoption (search.h) -- on ten kinds of input, both directions."""
+    import ctypes
+    from point_cloud_utils_amd import _Dev, _fn, Stats
+    rng = np.random.default_rng([SEED, 4242, len(dq), len(dr), dtype().itemsize])
+    n, m = int(rng.integers(30000, 120000)), int(rng.integers(30000, 120000))
+    x, y = make(rng, n, dq, dtype), make(rng, m, dr, dtype)
+    dxy, _ = pcu.k_nearest_neighbors(x, y, 1)
+    dyx, _ = pcu.k_nearest_neighbors(y, x, 1)
+    dv = _Dev(x, y); means = (ctypes.c_double * 2)(); st = Stats()
+    for _ in range(2):                                # (twice: both parities of the build's fill words, a warm context)
+        rc = _fn("chamfer", dv.suffix)(dv.ctx, dv.pa, n, dv.pb, m, 2.0, 10, ctypes.addressof(means), None, None, dv.flags, dv.stream, ctypes.addressof(st))
+        assert rc == 0
+        for got, rows, cnt in ((means[0], dxy, n), (means[1], dyx, m)):
+            want = float(np.asarray(rows).astype(np.float64).sum()) / cnt
+            assert abs(got - want) <= 1e-10 * want + 1e-300, (dq, dr, got, want)
