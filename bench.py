@@ -223,9 +223,11 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         cnt = counters()
         traffic = cnt.get("k_search1_flat_f32_bytes_per_launch")
-        roof = {"bound": "hbm", "actual_bound": "valu_issue",
+        roof = {"bound": "hbm", "actual_bound": "vmem_issue",
                 "bound_note": "`bound` is the roofline BASELINE.json designates (achieved = SURVEY 8d algorithmic bytes / launch time against the HBM peak); what the "
-                              "kernel actually runs into is vector-instruction issue (counters below), as SURVEY 8d's consistency note predicts for an exact pruned 3-D KNN",
+                              "kernel actually runs into is the CU's texture-address path -- ~20 cycles per vector-memory (gather) instruction whatever its width, "
+                              "vmem_insts_per_wave of them, ta_busy_frac -- with vector-ALU issue next (valu_busy_frac); DESIGN.md 4.2. It cannot be HBM-bound: "
+                              "SURVEY 8d's consistency note",
                 "kernel": "k_search1_flat<float> (both directions in one launch, fused Chamfer epilogue)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "measured_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
@@ -312,7 +314,7 @@ def config_roofline(cfg, alg, step_s, k_ms, k_calls):
     live_ms = k_ms / k_calls if k_calls else None
     prof_ms = ck["dominant_avg_us"] * ck.get("dominant_launches_per_call", 1.0) / 1e3 if ck.get("dominant_avg_us") else None
     achieved = alg / step_s / 1e9
-    roof = {"bound": "hbm", "actual_bound": ck.get("actual_bound", "valu_issue"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "actual_bound": ck.get("actual_bound", "vmem_issue / valu_issue (k = 1: gathers; k > 1: sorted insertion; DESIGN.md 4.2)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": ck.get("hbm_bytes_per_call"), "counters_commit": ck.get("commit"), "alg_bytes_per_call": alg,
             "note": "whole operator call (all launches + host) against SURVEY 8d's algorithmic bytes; traffic = measured HBM bytes of the whole call "
                     "(rocprofv3 --pmc, profiles/config_kernels.json: a tracked collection, see `source`)",
