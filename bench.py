@@ -13,11 +13,14 @@ Prints ONE JSON line on rank 0 (contract in the task description): metric/value 
   roofline      dominant kernel k_search1_flat<float> (both directions in one launch): SURVEY 8d algorithmic bytes of the
                 Chamfer row (24 B per query-point) / HIP-event launch time vs the 8 TB/s HBM peak; measured HBM traffic and the
                 issue-side counters (VALU busy, TA busy, SALU issue fraction, active lanes) come from profiles/hbm_traffic.json, which
-                profiles/postprocess.py derives from the round's rocprofv3 --pmc passes;
+                profiles/postprocess.py derives from the round's rocprofv3 --pmc passes (stamped with the commit they were collected at:
+                roofline.counters_commit);
   cpu_baseline  the reference's nanoflann path on this box's host cores (median of 3; search-only seconds beside it);
-  parity        the GPU result of the timed pair against the reference's result on the SAME arrays (value + both index arrays).
+  parity        the GPU result of the timed pair against the reference's result on the SAME arrays (value + both index arrays);
+  configs       (N = 1, behind the timed region; --no-configs skips it) every BASELINE config c1 .. c5 run through the same code as
+                ``--config cN``: ms_per_step, value, roofline, parity against the reference and its cpu_baseline per entry.
 
-Other BASELINE configs (parity-test cases): ``--config c2|c3|c4|c5`` prints the same kind of line for
+Other BASELINE configs (parity-test cases): ``--config c1|c2|c3|c4|c5`` prints the same kind of line for Chamfer 10k fp64,
 k_nearest_neighbors k=1 1M/1M, k=16 4M/4M, batched Hausdorff 256k pairs (32 pairs per GPU), Chamfer bunny-vs-1M f64.
 """
 import argparse
