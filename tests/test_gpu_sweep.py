@@ -188,3 +188,22 @@ def test_fused_sum_is_the_sum_of_the_rows(pcu, dtype, dq, dr):
         for got, rows, cnt in ((means[0], dxy, n), (means[1], dyx, m)):
             want = float(np.asarray(rows).astype(np.float64).sum()) / cnt
             assert abs(got - want) <= 1e-10 * want + 1e-300, (dq, dr, got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n,m", [(2047, 2047), (2048, 2048), (2049, 2047), (2047, 40000), (40000, 2047), (5000, 2049), (16383, 16384), (16384, 32767),
+                                 (32768, 2048), (3000, 100000), (100000, 3000)])
+def test_sizes_around_the_small_cloud_thresholds(pcu, oracle_kind, dtype, n, m):
+    """Round 5 moved two thresholds from 16384 / 32768 to 2048 (pcu_hip.hip: wave_only_below -- query clouds below it go wave-per-query from
+    the start -- and bucket_plan's minimum for the one-pass index build): every combination of the paths on either side of the old and new
+    values, all operators, one-shot and through a persistent index."""
+    rng = np.random.default_rng([SEED, 2048, n, m, dtype().itemsize])
+    q, r = rng.random((n, 3)).astype(dtype), rng.random((m, 3)).astype(dtype)
+    r[: min(m, 64)] = q[: min(m, 64)]                 # a few exact zero distances / duplicates across the clouds
+    for k in (1, 5):
+        check_all_operators(pcu, oracle_kind, q, r, min(k, m), f"thresholds n={n} m={m} k={k} {dtype.__name__}")
+    with pcu.DatasetIndex(r, k_hint=2) as index:
+        for k in (1, 3):
+            d, c = index.k_nearest_neighbors(q, k)
+            d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=oracle_kind)
+            assert np.array_equal(c, c0) and np.array_equal(np.asarray(d).view(np.uint8), np.asarray(d0).view(np.uint8)), (n, m, k)
