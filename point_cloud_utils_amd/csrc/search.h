@@ -1071,6 +1071,10 @@ __global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
     __shared__ uint2 s_rng[8][kBlock];
     int cnt = 0;
     auto flush = [&]() {
+#ifdef PCU_EXPERIMENT_NOINSERT          /* (scratch experiment: WRONG results; prices the insertion's share of the kernel) */
+        if (cnt > 0) { bd[K - 1] = s_bd[0][tid] < bd[K - 1] ? s_bd[0][tid] : bd[K - 1]; bi[K - 1] = s_bi[0][tid]; }
+        cnt = 0; return;
+#endif
         int mx = cnt;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
