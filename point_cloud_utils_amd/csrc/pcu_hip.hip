@@ -325,7 +325,7 @@ static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
 template <typename T>
 static size_t index_bytes(int64_t n, double occ) {
     int mc = max_cells_for(n, occ);
-    size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8) * 4, 256) + align_up(sorted_records_bytes((size_t)n, sizeof(Pt4<T>), sizeof(T)), 256) +
+    size_t b = align_up(sizeof(GridParams<T>), 256) + align_up((size_t)(mc + 1 + kBkMaxBuckets + 8 + 64) * 4, 256) + align_up(sorted_records_bytes((size_t)n, sizeof(Pt4<T>), sizeof(T)), 256) +
                2 * align_up((size_t)n * 4, 256) + align_up((size_t)(mc / kScanChunk + 2) * 4, 256) + align_up(kBboxBlocks * kBboxStride * sizeof(T), 256);
     int sh = 0, nb = 0;
     if (bucket_plan(n, occ, &sh, &nb))
@@ -339,7 +339,11 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
     g.n = (int)n; g.max_cells = max_cells_for(n, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
     g.bucketed = allow_bucketed && bucket_plan(n, occ, &g.shift, &g.nb_max);
     if (aalloc(a, &g.gp, 1)) return -1;
-    if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1 + kBkMaxBuckets + 8)) return -1;    // + bucket totals + large-bucket count (zeroed together)
+    // (cell_start sits 256 bytes INTO its block: the k = 1 / k > 1 lane kernels read the row table of a query in the first cell of the first row
+    // from one word BEFORE cell_start (search.h: "uniform four-word tables"; the word is never used, but its address must be mapped -- also when
+    // the block is an overflow hipMalloc of its own))
+    if (aalloc(a, &g.cell_start, (size_t)g.max_cells + 1 + kBkMaxBuckets + 8 + 64)) return -1;    // + bucket totals + large-bucket count (zeroed together)
+    g.cell_start += 64;
     if (a.alloc((void**)&g.sorted, sorted_records_bytes((size_t)n, sizeof(Pt4<T>), sizeof(T)))) return -1;        // + the +inf sentinel records + the coordinates-only copy (pcu_types.h: xyz_of)
     if (aalloc(a, &g.cell_of, (size_t)n)) return -1;
     if (aalloc(a, &g.rank, (size_t)n)) return -1;
