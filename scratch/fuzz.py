@@ -44,7 +44,9 @@ for case in range(first, ncases):
         if tg > 1.0: print(f'SLOW knn {tg:.2f} s', tag, pcu.last_stats(), flush=True)
         if V: print('  knn done', pcu.last_stats(), flush=True)
         d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
-        ok = np.array_equal(c, c0) and np.array_equal(d.view(np.uint8), d0.view(np.uint8))
+        # (n == k == 1: the product squeezes to 0-d -- numpy.squeeze semantics, unpinned in the reference -- the oracle's wrapper to (1,): compare squeezed)
+        ok = np.array_equal(np.squeeze(c), np.squeeze(c0)) and np.array_equal(np.atleast_1d(np.squeeze(d)).view(np.uint8), np.atleast_1d(np.squeeze(d0)).view(np.uint8))
+        if not ok: tag += f" KNN rows differing {int((np.atleast_1d(c) != np.atleast_1d(c0)).sum())} first c={np.atleast_2d(c)[:2]} c0={np.atleast_2d(c0)[:2]} d={np.atleast_2d(d)[:2]} d0={np.atleast_2d(d0)[:2]} stats={pcu.last_stats()}"
         if k == 1 and ok:
             if V: print('  hausdorff', flush=True)
             tg = time.time(); h = pcu.hausdorff_distance(q, r, return_index=True); tg = time.time() - tg
@@ -52,10 +54,14 @@ for case in range(first, ncases):
             h0 = oracle.hausdorff_distance(q, r, return_index=True, kind=kind)
             if V: print('  chamfer idx', flush=True)
             ch, cxy, cyx = pcu.chamfer_distance(q, r, return_index=True); ch0, cxy0, cyx0 = oracle.chamfer_distance(q, r, return_index=True, kind=kind)
-            ok = h == h0 and np.array_equal(cxy, cxy0) and np.array_equal(cyx, cyx0) and abs(float(ch) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30
+            parts = {"hausdorff": h == h0, "cxy": np.array_equal(cxy, cxy0), "cyx": np.array_equal(cyx, cyx0), "chamfer": abs(float(ch) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30}
             # the fused calls (no indices asked for)
             if V: print('  fused', flush=True)
-            ok = ok and abs(float(pcu.chamfer_distance(q, r)) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30 and pcu.hausdorff_distance(q, r) == h0[0]
+            chf = pcu.chamfer_distance(q, r); st_chf = pcu.last_stats(); hf = pcu.hausdorff_distance(q, r); st_hf = pcu.last_stats()
+            parts["chamfer_fused"] = abs(float(chf) - float(ch0)) <= 1e-4 * abs(float(ch0)) + 1e-30
+            parts["hausdorff_fused"] = hf == h0[0]
+            ok = all(parts.values())
+            if not ok: tag += f" FAILED {[k_ for k_, v_ in parts.items() if not v_]} h={h} h0={h0} ch={float(ch)!r} chf={float(chf)!r} ch0={float(ch0)!r} hf={hf!r} stats_chf={st_chf} stats_hf={st_hf}"
     except Exception as e:
         ok = False; tag += f" EXC {e!r}"
     if not ok:

@@ -56,8 +56,9 @@ def check_all_operators(pcu, kind, q, r, k, tag, bound_s=5.0):
     d, c = pcu.k_nearest_neighbors(q, r, k)
     assert time.perf_counter() - t0 < bound_s, (tag, "slow k_nearest_neighbors", pcu.last_stats())
     d0, c0 = oracle.k_nearest_neighbors(q, r, k, kind=kind)
-    assert np.array_equal(c, c0), (tag, pcu.last_stats())
-    assert np.array_equal(np.asarray(d).view(np.uint8), np.asarray(d0).view(np.uint8)), tag
+    # (n == k == 1: the product squeezes to 0-d -- numpy.squeeze semantics, unpinned in the reference -- the oracle's wrapper to (1,): compare squeezed)
+    assert np.array_equal(np.squeeze(c), np.squeeze(c0)), (tag, pcu.last_stats())
+    assert np.array_equal(np.atleast_1d(np.squeeze(d)).view(np.uint8), np.atleast_1d(np.squeeze(d0)).view(np.uint8)), tag
     if k != 1:
         return
     t0 = time.perf_counter()
