@@ -75,16 +75,21 @@ def test_sigint_raises_keyboard_interrupt(pcu, oracle_kind):
     if os.environ.get("PCU_HIP_NO_SIGINT", "0") not in ("", "0"):
         pytest.skip("PCU_HIP_NO_SIGINT: the library leaves the signal handlers alone")
     assert threading.current_thread() is threading.main_thread()
-    started = threading.Event()
+    started, left = threading.Event(), threading.Event()
     def killer():
         started.wait()
-        time.sleep(0.05)
+        if left.wait(0.05):           # the main thread has already left the guarded block (some other failure): do NOT interrupt pytest itself
+            return
         os.kill(os.getpid(), signal.SIGINT)
     th = threading.Thread(target=killer); th.start()
     t0 = time.perf_counter()
     try:
         with pytest.raises(KeyboardInterrupt):
-            _long_call(pcu, started)
+            try:
+                _long_call(pcu, started)
+            finally:
+                left.set()            # (set before the block is left, whatever leaves it; a SIGINT already on its way still lands inside pytest.raises)
+                started.set()
     finally:
         th.join()
     assert time.perf_counter() - t0 < 60.0            # 400 calls would take minutes
