@@ -102,3 +102,32 @@ def test_timing_switch_is_a_module_level_setting():
         assert pcu._flags() & _lib.TIME_KERNELS and not (pcu._flags() & _lib.TIME_PHASES)
     finally:
         pcu.set_timing(old)
+
+
+def test_sigint_handler_chains_to_the_interpreters():
+    """pcu_hip_watch_sigint (installed when the library is loaded, _lib.py) sits IN FRONT of Python's SIGINT handler and calls it: Ctrl-C must
+    still raise KeyboardInterrupt in the interpreter -- with the watch on, after switching it off (the previous handler is restored) and on
+    again. The reference's counterpart is its PyErr_CheckSignals() polling (/root/reference/src/point_cloud_distance.cpp:60-75, 96-98). No GPU
+    needed; the cancellation of a call in flight is tests/test_gpu_cancel.py."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import os, signal, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from point_cloud_utils_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "def hit():\n"
+        "    try:\n"
+        "        os.kill(os.getpid(), signal.SIGINT); time.sleep(2.0)\n"
+        "    except KeyboardInterrupt:\n"
+        "        return True\n"
+        "    return False\n"
+        "ok = [hit()]\n"
+        "assert L.pcu_hip_watch_sigint(0) == 0; ok.append(hit())\n"
+        "assert L.pcu_hip_watch_sigint(1) == 0; ok.append(hit())\n"
+        "L.pcu_hip_cancel()\n"
+        "print(ok)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("[True, True, True]"), (r.stdout, r.stderr[-2000:])
