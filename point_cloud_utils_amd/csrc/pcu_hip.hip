@@ -308,7 +308,7 @@ static int max_cells_for(int64_t n, double occ) {
 // which it grows with n like everything else; index_bytes() counts exactly what index_alloc() takes.
 static bool bucket_plan(int64_t n, double occ, int* shift, int* nb_max) {
     static const bool off = [] { const char* e = getenv("PCU_HIP_INDEX"); return e && strcmp(e, "atomic") == 0; }();
-    static const int64_t n_min = getenv("PCU_HIP_BUCKET_MIN") ? atoll(getenv("PCU_HIP_BUCKET_MIN")) : 2048;       // below: the atomic build (round 4: 32768; see wave_only_below)
+    static const int64_t n_min = getenv("PCU_HIP_BUCKET_MIN") ? atoll(getenv("PCU_HIP_BUCKET_MIN")) : 64;         // below: the atomic build (round 4: 32768; see wave_only_below)
     if (off || n < n_min || occ > 64.0) return false;
     const int mc = max_cells_for(n, occ);
     int sh = 5;
@@ -584,12 +584,12 @@ static double default_occupancy(int k) {
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 constexpr int kMaxKLane = 32;       // lane-per-query register slots (K = 64 needs 203-275 VGPRs: those k go wave-per-query from the start)
 constexpr int kMaxK = 127;          // the wave-per-query kernel holds k+1 <= 128 slots per lane
-// Fewer queries than this: wave-per-query from the start (PCU_HIP_WAVE_ONLY_BELOW overrides). Round 5: 16384 -> 2048, together with the one-pass
-// index build from 2048 points on (bucket_plan): a 10k-vs-10k call is then the same four launches as a 1M-vs-1M one (build x 2, lane pass, tail)
-// instead of thirteen (bbox, grid, 4 atomic-build passes per cloud, two wave-per-query launches, epilogue): config 1 0.159 -> 0.056 ms, the
-// 2 885-query direction of config 5 0.246 -> 0.201 ms (profiles/r05_small_ab.txt). 40 blocks of a lane pass do not fill the GPU -- a launch's
-// latency chain does not care.
-static int wave_only_below() { static const int v = getenv("PCU_HIP_WAVE_ONLY_BELOW") ? atoi(getenv("PCU_HIP_WAVE_ONLY_BELOW")) : 2048; return v; }
+// Fewer queries than this: wave-per-query from the start (PCU_HIP_WAVE_ONLY_BELOW overrides). Round 5: 16384 -> 64, together with the one-pass
+// index build from 64 points on (bucket_plan; round 4: 32768): a 10k-vs-10k call is then the same four launches as a 1M-vs-1M one (build x 2, lane
+// pass, tail) instead of thirteen (bbox, grid, 4 atomic-build passes per cloud, two wave-per-query launches, epilogue): config 1 0.159 -> 0.056 ms,
+// the 2 885-query direction of config 5 0.246 -> 0.201 ms, and clouds of 64 .. 2000 points 0.058-0.084 -> 0.044-0.055 ms per Chamfer
+// (profiles/r05_small_ab.txt). A handful of blocks of a lane pass do not fill the GPU -- a launch's latency chain does not care.
+static int wave_only_below() { static const int v = getenv("PCU_HIP_WAVE_ONLY_BELOW") ? atoi(getenv("PCU_HIP_WAVE_ONLY_BELOW")) : 64; return v; }
 #define kWaveOnlyBelow wave_only_below()
 constexpr double kSkewFactor = 32.0;    // dataset grid considered unbalanced when sum(count^2)/n > 32 x (occupancy + 1): a lane pass
                                         // costs ~30 us per unit of that ratio at 1M queries, a refit ~3 ms (scratch/skew.py)

@@ -192,12 +192,14 @@ def test_fused_sum_is_the_sum_of_the_rows(pcu, dtype, dq, dr):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("n,m", [(2047, 2047), (2048, 2048), (2049, 2047), (2047, 40000), (40000, 2047), (5000, 2049), (16383, 16384), (16384, 32767),
+@pytest.mark.parametrize("n,m", [(63, 63), (64, 64), (65, 63), (63, 5000), (5000, 63), (64, 100000), (100, 257), (1000, 1023), (1025, 700),
+                                 (2047, 2047), (2048, 2048), (2049, 2047), (2047, 40000), (40000, 2047), (5000, 2049), (16383, 16384), (16384, 32767),
                                  (32768, 2048), (3000, 100000), (100000, 3000)])
 def test_sizes_around_the_small_cloud_thresholds(pcu, oracle_kind, dtype, n, m):
-    """Round 5 moved two thresholds from 16384 / 32768 to 2048 (pcu_hip.hip: wave_only_below -- query clouds below it go wave-per-query from
-    the start -- and bucket_plan's minimum for the one-pass index build): every combination of the paths on either side of the old and new
-    values, all operators, one-shot and through a persistent index."""
+    """Round 5 moved two thresholds from 16384 / 32768 to 64 (pcu_hip.hip: wave_only_below -- query clouds below it go wave-per-query from
+    the start -- and bucket_plan's minimum for the one-pass index build; 2048 for most of the round): every combination of the paths on either
+    side of the old, the intermediate and the new values (and of the build's 1024-point sample), all operators, one-shot and through a
+    persistent index."""
     rng = np.random.default_rng([SEED, 2048, n, m, dtype().itemsize])
     q, r = rng.random((n, 3)).astype(dtype), rng.random((m, 3)).astype(dtype)
     r[: min(m, 64)] = q[: min(m, 64)]                 # a few exact zero distances / duplicates across the clouds
