@@ -202,7 +202,8 @@ def test_sizes_around_the_small_cloud_thresholds(pcu, oracle_kind, dtype, n, m):
     persistent index."""
     rng = np.random.default_rng([SEED, 2048, n, m, dtype().itemsize])
     q, r = rng.random((n, 3)).astype(dtype), rng.random((m, 3)).astype(dtype)
-    r[: min(m, 64)] = q[: min(m, 64)]                 # a few exact zero distances / duplicates across the clouds
+    c = min(n, m, 64)
+    r[:c] = q[:c]                                     # a few exact zero distances / duplicates across the clouds
     for k in (1, 5):
         check_all_operators(pcu, oracle_kind, q, r, min(k, m), f"thresholds n={n} m={m} k={k} {dtype.__name__}")
     with pcu.DatasetIndex(r, k_hint=2) as index:
