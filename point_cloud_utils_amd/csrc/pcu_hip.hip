@@ -65,6 +65,7 @@ static std::atomic<unsigned> g_cancel_epoch{0};
 static struct sigaction g_prev_sigint;
 static std::atomic<int> g_sigint_watched{0};
 static void pcu_on_sigint(int sig, siginfo_t* info, void* uc) {
+    if (!(g_prev_sigint.sa_flags & SA_SIGINFO) && g_prev_sigint.sa_handler == SIG_IGN) return;      // the host ignores SIGINT: so do the calls
     g_cancel.store(1, std::memory_order_relaxed);
     if (g_prev_sigint.sa_flags & SA_SIGINFO) { if (g_prev_sigint.sa_sigaction) g_prev_sigint.sa_sigaction(sig, info, uc); }
     else if (g_prev_sigint.sa_handler != SIG_DFL && g_prev_sigint.sa_handler != SIG_IGN && g_prev_sigint.sa_handler) g_prev_sigint.sa_handler(sig);

@@ -128,6 +128,10 @@ def test_sigint_handler_chains_to_the_interpreters():
         "assert L.pcu_hip_watch_sigint(0) == 0; ok.append(hit())\n"
         "assert L.pcu_hip_watch_sigint(1) == 0; ok.append(hit())\n"
         "L.pcu_hip_cancel()\n"
+        "# a host that ignores SIGINT when the watch is installed keeps ignoring it\n"
+        "assert L.pcu_hip_watch_sigint(0) == 0\n"
+        "signal.signal(signal.SIGINT, signal.SIG_IGN); assert L.pcu_hip_watch_sigint(1) == 0\n"
+        "os.kill(os.getpid(), signal.SIGINT); time.sleep(0.2); ok.append('ignored')\n"
         "print(ok)\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.strip().endswith("[True, True, True]"), (r.stdout, r.stderr[-2000:])
+    assert r.returncode == 0 and r.stdout.strip().endswith("[True, True, True, 'ignored']"), (r.stdout, r.stderr[-2000:])
