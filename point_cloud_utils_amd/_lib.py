@@ -32,6 +32,27 @@ class Stats(ctypes.Structure):
 _lib = None
 _lock = threading.RLock()
 
+CANCEL_BY_REQUEST = 1       # pcu_hip_cancel_source(): pcu_hip_cancel() ...
+CANCEL_BY_SIGINT = 2        # ... or the chained SIGINT handler
+
+_COMPUTE_ENTRY_POINTS = [f"pcu_hip_{op}_{suf}" for suf in ("f32", "f64") for op in (
+    "knn", "one_sided_hausdorff", "hausdorff", "chamfer", "index_create", "index_knn", "hausdorff_batch", "chamfer_batch", "normals_knn",
+    "normals_ball", "dedup", "pairwise", "sinkhorn", "dot", "debug_kd_tree")] + [
+    "pcu_hip_morton_encode", "pcu_hip_morton_decode", "pcu_hip_morton_addsub", "pcu_hip_morton_knn"] + [
+    f"pcu_hip_voxel_downsample_{sp}_{sa}" for sp in ("f32", "f64") for sa in ("f32", "f64")]
+
+
+def _after_call(rc, func, arguments):
+    """ctypes errcheck of every compute entry point. A call that SIGINT made return early is decided by the interpreter's own handler,
+    as in the reference (`if (PyErr_CheckSignals() != 0) throw`): PyErr_CheckSignals runs the pending Python-level handlers on the main
+    thread -- the default one raises KeyboardInterrupt, which leaves through here; if nothing was raised (a handler that only takes note, or
+    a worker thread: the reference's workers see 0 too) the abandoned call is run again with the same arguments. An explicit
+    pcu.cancel() always ends the call (check() raises KeyboardInterrupt)."""
+    if rc == ERR_CANCELLED and _lib is not None and _lib.pcu_hip_cancel_source() == CANCEL_BY_SIGINT:
+        ctypes.pythonapi.PyErr_CheckSignals()        # (PyDLL: an exception set by the handler is raised from this line)
+        return func(*arguments)
+    return rc
+
 
 def _preload_hip_runtime():
     """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7)
@@ -105,11 +126,17 @@ def lib():
         L.pcu_hip_index_destroy.restype = None
         L.pcu_hip_cancel.restype = None
         L.pcu_hip_watch_sigint.argtypes = [ci]
-        # Ctrl-C during a long call (the reference: PyErr_CheckSignals per query -> KeyboardInterrupt, src/point_cloud_distance.cpp:60-75,96-98): the
-        # library chains a SIGINT handler in front of Python's, so a call in flight returns early and the interpreter raises KeyboardInterrupt.
+        L.pcu_hip_cancel_source.restype = ci
+        # Ctrl-C during a long call. The reference polls PyErr_CheckSignals() per query and aborts when it returns non-zero, i.e. when the
+        # interpreter's SIGINT handler RAISES (src/point_cloud_distance.cpp:60-75, 96-98): KeyboardInterrupt with the default handler; a custom
+        # handler that only records the request lets the computation finish. Same here: the library chains a C handler in front of the
+        # installed one (pcu_hip_watch_sigint), a call in flight returns PCU_HIP_ERR_CANCELLED early, and _after_call() below then asks the
+        # interpreter (PyErr_CheckSignals): a raising handler ends the call with its exception, a non-raising one has the call run again.
         # PCU_HIP_NO_SIGINT=1 leaves the process's signal handlers alone (then a call runs to its end before the interrupt is seen).
         if os.environ.get("PCU_HIP_NO_SIGINT", "0") in ("", "0"):
             L.pcu_hip_watch_sigint(1)
+        for name in _COMPUTE_ENTRY_POINTS:
+            getattr(L, name).errcheck = _after_call
         _lib = L
     return _lib
 
@@ -188,6 +215,6 @@ def check(rc):
     msg = last_error()
     if rc == ERR_INVALID:
         raise ValueError(msg)
-    if rc == ERR_CANCELLED:         # (after SIGINT the interpreter raises its own KeyboardInterrupt before this line; this is pcu_hip_cancel() from a thread)
+    if rc == ERR_CANCELLED:         # pcu_hip_cancel() from another thread (a SIGINT was settled by _after_call: the interpreter's handler raised, or the call was re-run)
         raise KeyboardInterrupt(msg)
     raise RuntimeError(f"libpcu_hip: {msg}")

@@ -1063,6 +1063,7 @@ struct KdSearchArgs {
     int k, squared, row_out;
     T* out_d; long long* out_i;
     void* stack; int stack_cap;         // per work item: stack_cap frames (tree depth + 2) in global memory
+    int t0 = 0;                         // k_kd_search: first query of this launch (long query lists are enqueued in pieces, pcu_hip.hip: kd_search_launch)
     int* error_flag;
     // whole-cloud mode (k beyond the grid search's capacity, kd_search<T, true>): queries are the raw (nq, 3) rows, every block
     // strides over them, the result set lives in dynamic LDS (rs_d == nullptr) or in a per-block global scratch of k slots
@@ -1214,7 +1215,7 @@ __device__ __forceinline__ void kd_search_one(const KdSearchArgs<T>& a, const in
 
 template <typename T>
 __global__ __launch_bounds__(64) void k_kd_search(const KdSearchArgs<T> a) {
-    const int t = blockIdx.x;
+    const int t = a.t0 + (int)blockIdx.x;
     if (t >= *a.qcount_dev) return;
     __shared__ T rd[128]; __shared__ int ri[128];                       // KNNResultSet storage (k <= 128)
     __shared__ T s_dists[3]; __shared__ T s_vec[3];                     // indexed by the split dimension: kept in LDS so

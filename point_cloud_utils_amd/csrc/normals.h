@@ -31,11 +31,15 @@ __device__ inline void smallest_eigenvector(const Sym3& S, double& nx, double& n
 #pragma unroll
         for (int j = 0; j < 3; ++j) a[i][j] *= sc;
     double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    bool last = false;
     for (int sweep = 0; sweep < 12; ++sweep) {
-        // (the matrix is scaled to trace 1 and cyclic Jacobi converges quadratically: once the off-diagonal mass is below 1e-20 another sweep
-        // moves the eigenvectors by less than one part in 1e-19 of the eigenvalue gaps -- round 4 ran all twelve sweeps for every point)
+        // (the matrix is scaled to trace 1 and cyclic Jacobi converges quadratically. An eigenvector is off by ~ off / gap, and thin
+        // neighbourhoods -- near-collinear points: two eigenvalues of 1e-8 and 1e-16 -- have gaps far below 1: so the sweeps stop ONE SWEEP AFTER
+        // the off-diagonal mass has fallen below 1e-20 (that sweep squares it: beyond double precision for any gap the data can resolve), not at
+        // the threshold itself; round 4 ran all twelve sweeps for every point, round 5 stopped at the threshold)
         const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        if (off < 1e-20) break;
+        if (last || off == 0.0) break;
+        last = off < 1e-20;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int p = r == 2 ? 1 : 0, q = r == 0 ? 1 : 2;                 // (0,1), (0,2), (1,2)
@@ -43,7 +47,7 @@ __device__ inline void smallest_eigenvector(const Sym3& S, double& nx, double& n
             if (fabs(apq) < 1e-300) continue;
             const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
             const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = rsqrt(t * t + 1.0), s = t * c;
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;          // (correctly rounded: rsqrt() is not, and the rotations accumulate in v)
             a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = 0; a[q][p] = 0;
             const int o = 3 - p - q;                                           // the third index
             const double aop = a[o][p], aoq = a[o][q];

@@ -40,12 +40,16 @@ using namespace pcu;
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
+static thread_local int g_fail_code = 0;       // code of this thread's last fail(): internal layers pass "failed" up as -1 (their positive codes mean other
+                                               // things), the ABI boundary returns the code the failure was recorded with (abi_rc)
 static int fail(int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     g_err = buf;
+    g_fail_code = code;
     return code;
 }
+static inline int abi_rc(int rc) { return rc < 0 && g_fail_code < 0 ? g_fail_code : rc; }
 #define HIP_TRY(x)                                                                              \
     do { hipError_t e_ = (x); if (e_ != hipSuccess)                                             \
         return fail(PCU_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -53,30 +57,69 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------ cancellation
 // The reference polls PyErr_CheckSignals() per query and per kd-tree node and turns Ctrl-C into KeyboardInterrupt
 // (src/point_cloud_distance.cpp:60-75, 96-98; external/nanoflann/nanoflann.hpp:1004). Here a call is a sequence of host phases (enqueue, wait,
-// decide, enqueue ...), and every host wait is a bounded poll that also looks at one process-wide flag:
-//   pcu_hip_cancel()            sets it (any thread, async-signal-safe);
-//   pcu_hip_watch_sigint(1)     chains a SIGINT handler in front of the installed one (Python's): it sets the flag and then calls the previous
-//                               handler, so the interpreter still records its KeyboardInterrupt -- which it raises as soon as the C call returns.
-// A call that sees the flag stops enqueuing, drains the device (kernels cannot be killed; what is queued is one phase: milliseconds), and
-// returns PCU_HIP_ERR_CANCELLED. Every entry point clears the flag on entry (DeviceGuard). Contexts reset their cross-call device state
-// (the "no memset" fill words, the speculative tree top) when they see that a call was abandoned since their last one (g_cancel_epoch).
-static std::atomic<int> g_cancel{0};
+// decide, enqueue ...), and every host wait is a bounded poll that also looks at one process-wide request counter:
+//   pcu_hip_cancel()            bumps it (any thread, async-signal-safe);
+//   pcu_hip_watch_sigint(1)     chains a SIGINT handler in front of the installed one (Python's): it bumps the counter and then calls the previous
+//                               handler, so the interpreter still records the signal for its own handler -- which decides (the Python side asks
+//                               it through PyErr_CheckSignals, as the reference does: _lib.py: _after_call).
+// A compute entry point notes the counter on entry (CallGuard); a request made while the call is in flight makes the two differ: the call stops
+// enqueuing, drains ITS streams (kernels cannot be killed; what is queued is one phase: milliseconds), and returns PCU_HIP_ERR_CANCELLED. A
+// request is for the calls in flight: one made between two calls is not remembered (after a SIGINT the interpreter raises between the calls
+// anyway). Entry points that do no work (context / index create and destroy) neither note nor clear anything, so a lane created in the middle
+// of a batch call, or a context destroyed by another thread or the garbage collector, cannot swallow a request. Contexts reset their cross-call
+// device state (the "no memset" fill words, the speculative tree top) when they see that a call was abandoned since their last one
+// (g_cancel_epoch).
+static std::atomic<unsigned> g_cancel_gen{0};          // number of requests so far
+static std::atomic<int> g_cancel_source{0};            // who made the last one: PCU_HIP_CANCEL_BY_REQUEST / PCU_HIP_CANCEL_BY_SIGINT
+static thread_local unsigned t_call_gen = 0;           // g_cancel_gen when this thread's current call began
 static std::atomic<unsigned> g_cancel_epoch{0};
 static struct sigaction g_prev_sigint;
 static std::atomic<int> g_sigint_watched{0};
+static std::atomic<int> g_in_sigint{0};
 static void pcu_on_sigint(int sig, siginfo_t* info, void* uc) {
-    if (!(g_prev_sigint.sa_flags & SA_SIGINFO) && g_prev_sigint.sa_handler == SIG_IGN) return;      // the host ignores SIGINT: so do the calls
-    g_cancel.store(1, std::memory_order_relaxed);
-    if (g_prev_sigint.sa_flags & SA_SIGINFO) { if (g_prev_sigint.sa_sigaction) g_prev_sigint.sa_sigaction(sig, info, uc); }
-    else if (g_prev_sigint.sa_handler != SIG_DFL && g_prev_sigint.sa_handler != SIG_IGN && g_prev_sigint.sa_handler) g_prev_sigint.sa_handler(sig);
-    else if (g_prev_sigint.sa_handler == SIG_DFL) { signal(SIGINT, SIG_DFL); raise(SIGINT); }        // no handler before ours: the default action
+    // (a handler installed over ours that chains back to ours, and over which ours was re-armed, would recurse: the inner visit returns at once)
+    if (g_in_sigint.exchange(1)) return;
+    const struct sigaction prev = g_prev_sigint;
+    if ((prev.sa_flags & SA_SIGINFO) || prev.sa_handler != SIG_IGN) {                                 // the host ignores SIGINT: so do the calls
+        g_cancel_source.store(PCU_HIP_CANCEL_BY_SIGINT, std::memory_order_relaxed);
+        g_cancel_gen.fetch_add(1, std::memory_order_relaxed);
+        if (prev.sa_flags & SA_SIGINFO) { if (prev.sa_sigaction && prev.sa_sigaction != pcu_on_sigint) prev.sa_sigaction(sig, info, uc); }
+        else if (prev.sa_handler != SIG_DFL && prev.sa_handler) prev.sa_handler(sig);
+        else if (prev.sa_handler == SIG_DFL) { g_in_sigint.store(0); signal(SIGINT, SIG_DFL); raise(SIGINT); return; }   // no handler before ours: the default action
+    }
+    g_in_sigint.store(0);
 }
-static int cancelled() {
-    (void)hipDeviceSynchronize();                  // nothing of the abandoned call may still be running when its buffers are reused or freed
+static int sigint_install() {
+    struct sigaction sa; memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = pcu_on_sigint; sa.sa_flags = SA_SIGINFO | SA_RESTART; sigemptyset(&sa.sa_mask);
+    struct sigaction old;
+    if (sigaction(SIGINT, &sa, &old) != 0) return -1;
+    g_prev_sigint = old;
+    return 0;
+}
+// Somebody replaced the handler after pcu_hip_watch_sigint(1) (Python's signal.signal() does: ipykernel, a graceful-shutdown hook): chain in
+// front of the new one, or Ctrl-C would silently stop reaching the calls. One sigaction() query per compute call (~0.2 us).
+static void sigint_rearm() {
+    if (!g_sigint_watched.load(std::memory_order_relaxed)) return;
+    struct sigaction cur;
+    if (sigaction(SIGINT, nullptr, &cur) != 0) return;
+    if ((cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == pcu_on_sigint) return;
+    (void)sigint_install();
+}
+__attribute__((destructor)) static void sigint_unchain_at_unload() {       // (dlclose / exit: never leave a handler behind that points into an unmapped library)
+    struct sigaction cur;
+    if (g_sigint_watched.exchange(0) && sigaction(SIGINT, nullptr, &cur) == 0 && (cur.sa_flags & SA_SIGINFO) && cur.sa_sigaction == pcu_on_sigint)
+        (void)sigaction(SIGINT, &g_prev_sigint, nullptr);
+}
+struct pcu_hip_ctx;
+static thread_local pcu_hip_ctx* t_call_ctx = nullptr;          // the context of this thread's current call (drain_call)
+static void drain_call(hipStream_t s);
+static int cancelled(hipStream_t s) {
+    drain_call(s);                                 // nothing of the abandoned call may still be running when its buffers are reused or freed
     g_cancel_epoch.fetch_add(1, std::memory_order_relaxed);
     return fail(PCU_HIP_ERR_CANCELLED, "cancelled (pcu_hip_cancel / SIGINT) while waiting for the GPU");
 }
-static inline bool cancel_requested() { return g_cancel.load(std::memory_order_relaxed) != 0; }
+static inline bool cancel_requested() { return g_cancel_gen.load(std::memory_order_relaxed) != t_call_gen; }
 // hipStreamSynchronize as a bounded poll: tight for the first 2 ms (short calls keep their latency), then 50 us naps.
 static int wait_stream(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -85,12 +128,22 @@ static int wait_stream(hipStream_t s) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return 0;
         if (e != hipErrorNotReady) return fail(PCU_HIP_ERR_RUNTIME, "hipStreamQuery failed: %s", hipGetErrorString(e));
-        if (cancel_requested()) return cancelled();
+        if (cancel_requested()) return cancelled(s);
         if (!nap && (it & 0x3f) == 0x3f && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) nap = true;
         if (nap) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
     }
 }
 #define HIP_WAIT(s) do { const int w_ = wait_stream(s); if (w_) return w_; } while (0)
+// The same for an event recorded on stream s (long launches are enqueued in pieces with at most two in the queue: see kd_search_launch).
+static int wait_event(hipEvent_t ev, hipStream_t s) {
+    for (unsigned it = 0;; ++it) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(PCU_HIP_ERR_RUNTIME, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if (cancel_requested()) return cancelled(s);
+        if (it > 64) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
+    }
+}
 
 // Host-side profile of a call (PCU_HIP_HOST_PROF=1; diagnostics): wall-clock marks at entry, first launch, last launch, result seen, exit;
 // the mean spans of every 1000 calls go to stderr. Tells the Python wrapper's share of a step from the library's (scratch/hostgap.py).
@@ -134,6 +187,7 @@ struct pcu_hip_ctx {
     size_t extra_hint = 0;                    // largest overflow seen: added to the arena request of later calls
     hipEvent_t ev[8] = {};
     hipEvent_t kev[8] = {};                    // brackets of the main (pass-0) search launches of a call
+    hipEvent_t cev[2] = {};                    // progress marks of a launch that is enqueued in pieces (kd_search_launch; created on first use)
     int n_kev = 0;
     double occupancy = 0;                      // <=0: default
     int* h_pinned = nullptr;                   // small pinned readback buffer
@@ -179,7 +233,6 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct DeviceGuard {
     int prev = -1, dev = -1;
     explicit DeviceGuard(int device) : dev(device) {
-        g_cancel.store(0, std::memory_order_relaxed);     // (every entry point constructs one guard first: a cancellation request is for the call in flight)
         if (dev < 0) return;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) (void)hipSetDevice(dev);
@@ -187,6 +240,27 @@ struct DeviceGuard {
     ~DeviceGuard() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete; DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+
+// Compute entry points: the device guard + the call's view of the cancellation counter, a clean failure code, the SIGINT chain re-armed.
+struct CallGuard : DeviceGuard {
+    explicit CallGuard(pcu_hip_ctx* c) : DeviceGuard(c ? c->device : -1) {
+        t_call_ctx = c;
+        t_call_gen = g_cancel_gen.load(std::memory_order_relaxed);
+        g_fail_code = 0;
+        sigint_rearm();
+    }
+    ~CallGuard() { t_call_ctx = nullptr; }
+};
+// An abandoned call waits for what it enqueued: the stream it was given, its context's own / auxiliary / speculative streams and its lanes'
+// -- not for the whole device (other threads' and the host application's streams keep running).
+static void drain_ctx(pcu_hip_ctx* c) {
+    for (hipStream_t q : {c->own_stream, c->aux_stream, c->spec_stream}) if (q) (void)hipStreamSynchronize(q);
+    for (pcu_hip_ctx* l : c->lanes) drain_ctx(l);
+}
+static void drain_call(hipStream_t s) {
+    if (s) (void)hipStreamSynchronize(s);
+    if (t_call_ctx) drain_ctx(t_call_ctx); else (void)hipDeviceSynchronize();
+}
 
 struct Arena {
     pcu_hip_ctx* c;
@@ -1156,6 +1230,30 @@ static void kd_speculate_end(pcu_hip_ctx* c, bool call_completed) {
     if (sp.active) { sp.active = false; if (call_completed) c->kd_spec_hint = false; }
 }
 
+// The tie-order traversal of n queries (one wave each). A call whose queries are nearly all tied -- a cloud against a line, a lattice -- runs
+// hundreds of milliseconds here, and a kernel cannot be abandoned: beyond kKdSearchPiece queries the launch is enqueued in pieces, at most two
+// in the queue, the host waiting (cancellably) for piece i - 1 before it enqueues piece i + 1. The GPU never idles between pieces; a
+// cancellation request is honoured within about one piece (~30 ms of traversal).
+constexpr int kKdSearchPiece = 16384;
+template <typename T>
+static int kd_search_launch(pcu_hip_ctx* c, hipStream_t s, KdSearchArgs<T> a, int n) {
+    if (n <= kKdSearchPiece) {
+        a.t0 = 0;
+        hipLaunchKernelGGL(k_kd_search<T>, dim3(n), dim3(64), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    for (auto& e : c->cev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int t0 = 0, i = 0; t0 < n; t0 += kKdSearchPiece, ++i) {
+        a.t0 = t0;
+        hipLaunchKernelGGL(k_kd_search<T>, dim3(std::min(kKdSearchPiece, n - t0)), dim3(64), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->cev[i & 1], s));
+        if (i >= 1) { if (int w = wait_event(c->cev[(i - 1) & 1], s)) return w; }
+    }
+    return 0;
+}
+
 template <typename T>
 static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob<T>& j, int n_tt, pcu_hip_stats* st) {
     c->kd_spec_hint = j.ridx.n >= kKdSpecMinPoints;          // genuine ties: calls like this one will probably have them again
@@ -1181,8 +1279,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         a.stack_cap = levels + 2;
         if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
         a.stack = frames;
-        hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
-        HIP_TRY(hipGetLastError());
+        if (kd_search_launch(c, s, a, n_tt)) return -1;
         int hc[16] = {0};                  // the build's counters: [3] = the traversal's error flag, [9] = a node held elements equal to its cut value
         HIP_TRY(hipMemcpyAsync(hc, err - 3, sizeof hc, hipMemcpyDeviceToHost, s));
         HIP_WAIT(s);
@@ -1198,8 +1295,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
             a.stack_cap = depth + 3;
             if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
             a.stack = frames;
-            hipLaunchKernelGGL(k_kd_search<T>, dim3(n_tt), dim3(64), 0, s, a);
-            HIP_TRY(hipGetLastError());
+            if (kd_search_launch(c, s, a, n_tt)) return -1;
             HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_WAIT(s);
         }
@@ -1847,7 +1943,7 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
         for (unsigned it = 0;; ++it) {
             if ((unsigned)*flag == c->seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
             if ((it & 0x3ff) == 0x3ff) {
-                if (cancel_requested()) return cancelled();
+                if (cancel_requested()) return cancelled(s);
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // long call or fault: poll the stream instead
             }
         }
@@ -2532,12 +2628,11 @@ int pcu_hip_device_count(void) {
     return n;
 }
 
-void pcu_hip_cancel(void) { g_cancel.store(1, std::memory_order_relaxed); }
+void pcu_hip_cancel(void) { g_cancel_source.store(PCU_HIP_CANCEL_BY_REQUEST, std::memory_order_relaxed); g_cancel_gen.fetch_add(1, std::memory_order_relaxed); }
+int pcu_hip_cancel_source(void) { return g_cancel_source.load(std::memory_order_relaxed); }
 int pcu_hip_watch_sigint(int enable) {
     if (enable && !g_sigint_watched.exchange(1)) {
-        struct sigaction sa; memset(&sa, 0, sizeof sa);
-        sa.sa_sigaction = pcu_on_sigint; sa.sa_flags = SA_SIGINFO | SA_RESTART; sigemptyset(&sa.sa_mask);
-        if (sigaction(SIGINT, &sa, &g_prev_sigint) != 0) { g_sigint_watched.store(0); return fail(PCU_HIP_ERR_RUNTIME, "sigaction(SIGINT) failed"); }
+        if (sigint_install() != 0) { g_sigint_watched.store(0); return fail(PCU_HIP_ERR_RUNTIME, "sigaction(SIGINT) failed"); }
     } else if (!enable && g_sigint_watched.exchange(0)) {
         struct sigaction cur;
         // (only if ours is still the installed handler: somebody who installed theirs after us keeps it)
@@ -2594,6 +2689,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (c->kd_ws) (void)hipFree(c->kd_ws);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->kev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->cev) if (e) (void)hipEventDestroy(e);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -2605,31 +2701,31 @@ int pcu_hip_ctx_set_cell_occupancy(pcu_hip_ctx* c, double ppc) { if (!c) return 
 int64_t pcu_hip_ctx_workspace_bytes(pcu_hip_ctx* c) { return c ? (int64_t)c->arena_cap : 0; }
 
 int pcu_hip_knn_f32(pcu_hip_ctx* c, const float* q, int64_t nq, const float* r, int64_t nr, int k, int max_leaf, float* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return knn_impl<float>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
+                    unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(knn_impl<float>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st)); }
 int pcu_hip_knn_f64(pcu_hip_ctx* c, const double* q, int64_t nq, const double* r, int64_t nr, int k, int max_leaf, double* od, int64_t* oi,
-                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return knn_impl<double>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st); }
+                    unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(knn_impl<double>(c, q, nq, r, nr, k, max_leaf, od, oi, flags, stream, st)); }
 
 int pcu_hip_one_sided_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<float>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(hausdorff_impl<float>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st)); }
 int pcu_hip_one_sided_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
-                                    unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<double>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st); }
+                                    unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(hausdorff_impl<double>(c, a, na, b, nb, false, max_leaf, od, oi, oj, flags, stream, st)); }
 int pcu_hip_hausdorff_f32(pcu_hip_ctx* c, const float* a, int64_t na, const float* b, int64_t nb, int max_leaf, float* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<float>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
+                          unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(hausdorff_impl<float>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st)); }
 int pcu_hip_hausdorff_f64(pcu_hip_ctx* c, const double* a, int64_t na, const double* b, int64_t nb, int max_leaf, double* od, int64_t* oi, int64_t* oj,
-                          unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return hausdorff_impl<double>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st); }
+                          unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(hausdorff_impl<double>(c, a, na, b, nb, true, max_leaf, od, oi, oj, flags, stream, st)); }
 
 int pcu_hip_chamfer_f32(pcu_hip_ctx* c, const float* x, int64_t nx, const float* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return chamfer_impl<float>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+                        unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(chamfer_impl<float>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st)); }
 int pcu_hip_chamfer_f64(pcu_hip_ctx* c, const double* x, int64_t nx, const double* y, int64_t ny, double p, int max_leaf, double* om, int64_t* cxy, int64_t* cyx,
-                        unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return chamfer_impl<double>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st); }
+                        unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(chamfer_impl<double>(c, x, nx, y, ny, p, max_leaf, om, cxy, cyx, flags, stream, st)); }
 
 #define PCU_BATCH_HAUSDORFF(SUF, T)                                                                                                         \
 int pcu_hip_hausdorff_batch_##SUF(pcu_hip_ctx* c, int n_pairs, const T* const* xs, const int64_t* nxs, const T* const* ys, const int64_t* nys,   \
                                   int max_leaf, T* out_d2, int64_t* out_i2, int64_t* out_j2, unsigned flags, void* stream, pcu_hip_stats* st) {  \
-    DeviceGuard dg(c ? c->device : -1);                                                                                                     \
-    return batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
+    CallGuard dg(c);                                                                                                     \
+    return abi_rc(batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
         [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p, unsigned lf, pcu_hip_stats* ls) { return hausdorff_begin<T>(l, xs[p], nxs[p], ys[p], nys[p], true, max_leaf, lf, nullptr, ls, pp); }, \
-        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return hausdorff_end<T>(l, pp, out_d2 + 2 * (size_t)p, out_i2 + 2 * (size_t)p, out_j2 + 2 * (size_t)p); });        \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return hausdorff_end<T>(l, pp, out_d2 + 2 * (size_t)p, out_i2 + 2 * (size_t)p, out_j2 + 2 * (size_t)p); }));       \
 }
 PCU_BATCH_HAUSDORFF(f32, float)
 PCU_BATCH_HAUSDORFF(f64, double)
@@ -2637,81 +2733,81 @@ PCU_BATCH_HAUSDORFF(f64, double)
 #define PCU_BATCH_CHAMFER(SUF, T)                                                                                                           \
 int pcu_hip_chamfer_batch_##SUF(pcu_hip_ctx* c, int n_pairs, const T* const* xs, const int64_t* nxs, const T* const* ys, const int64_t* nys,     \
                                 double p_norm, int max_leaf, double* out_mean2, unsigned flags, void* stream, pcu_hip_stats* st) {          \
-    DeviceGuard dg(c ? c->device : -1);                                                                                                     \
-    return batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
+    CallGuard dg(c);                                                                                                     \
+    return abi_rc(batch_run<T>(c, n_pairs, flags, stream, st,                                                                                      \
         [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p, unsigned lf, pcu_hip_stats* ls) { return chamfer_begin<T>(l, xs[p], nxs[p], ys[p], nys[p], p_norm, max_leaf, nullptr, nullptr, lf, nullptr, ls, pp); }, \
-        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return chamfer_end<T>(l, pp, out_mean2 + 2 * (size_t)p); });                             \
+        [&](pcu_hip_ctx* l, PendingPair<T>& pp, int p) { return chamfer_end<T>(l, pp, out_mean2 + 2 * (size_t)p); }));                            \
 }
 PCU_BATCH_CHAMFER(f32, float)
 PCU_BATCH_CHAMFER(f64, double)
 #undef PCU_BATCH_CHAMFER
 int pcu_hip_normals_knn_f32(pcu_hip_ctx* c, const float* p, int64_t n, const float* dirs, int k, int max_leaf, double drop, float* out_n, uint8_t* keep,
-                            unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return normals_knn_impl<float>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st); }
+                            unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(normals_knn_impl<float>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st)); }
 int pcu_hip_normals_knn_f64(pcu_hip_ctx* c, const double* p, int64_t n, const double* dirs, int k, int max_leaf, double drop, double* out_n, uint8_t* keep,
-                            unsigned flags, void* stream, pcu_hip_stats* st) { DeviceGuard dg(c ? c->device : -1); return normals_knn_impl<double>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st); }
+                            unsigned flags, void* stream, pcu_hip_stats* st) { CallGuard dg(c); return abi_rc(normals_knn_impl<double>(c, p, n, dirs, k, max_leaf, drop, out_n, keep, flags, stream, st)); }
 int pcu_hip_normals_ball_f32(pcu_hip_ctx* c, const float* p, int64_t n, const float* dirs, double radius, int min_pts, int max_pts, int weight_rbf, double drop,
                              float* out_n, uint8_t* keep, unsigned flags, void* stream, pcu_hip_stats* st) {
-    DeviceGuard dg(c ? c->device : -1); return normals_ball_impl<float>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st); }
+    CallGuard dg(c); return abi_rc(normals_ball_impl<float>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st)); }
 int pcu_hip_normals_ball_f64(pcu_hip_ctx* c, const double* p, int64_t n, const double* dirs, double radius, int min_pts, int max_pts, int weight_rbf, double drop,
                              double* out_n, uint8_t* keep, unsigned flags, void* stream, pcu_hip_stats* st) {
-    DeviceGuard dg(c ? c->device : -1); return normals_ball_impl<double>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st); }
+    CallGuard dg(c); return abi_rc(normals_ball_impl<double>(c, p, n, dirs, radius, min_pts, max_pts, weight_rbf, drop, out_n, keep, flags, stream, st)); }
 
 int pcu_hip_morton_encode(pcu_hip_ctx* c, const int32_t* pts, int64_t n, uint64_t* codes, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<int32_t, int32_t>(c, 0, pts, nullptr, n, codes, flags, stream); }
+    CallGuard dg(c); return abi_rc(morton_map_impl<int32_t, int32_t>(c, 0, pts, nullptr, n, codes, flags, stream)); }
 int pcu_hip_morton_decode(pcu_hip_ctx* c, const uint64_t* codes, int64_t n, int32_t* pts, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<uint64_t, uint64_t>(c, 1, codes, nullptr, n, pts, flags, stream); }
+    CallGuard dg(c); return abi_rc(morton_map_impl<uint64_t, uint64_t>(c, 1, codes, nullptr, n, pts, flags, stream)); }
 int pcu_hip_morton_addsub(pcu_hip_ctx* c, const uint64_t* c1, const uint64_t* c2, int64_t n, int subtract, uint64_t* out, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return morton_map_impl<uint64_t, uint64_t>(c, subtract ? 3 : 2, c1, c2, n, out, flags, stream); }
+    CallGuard dg(c); return abi_rc(morton_map_impl<uint64_t, uint64_t>(c, subtract ? 3 : 2, c1, c2, n, out, flags, stream)); }
 int pcu_hip_morton_knn(pcu_hip_ctx* c, const uint64_t* codes, int64_t n, const uint64_t* qcodes, int64_t m, int k, int sort_dist, int64_t* out_nn, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return morton_knn_impl<uint64_t>(c, codes, n, qcodes, m, k, sort_dist, out_nn, flags, stream); }
+    CallGuard dg(c); return abi_rc(morton_knn_impl<uint64_t>(c, codes, n, qcodes, m, k, sort_dist, out_nn, flags, stream)); }
 #define PCU_VOXEL(SUF, T, A)                                                                                                                        \
 int pcu_hip_voxel_downsample_##SUF(pcu_hip_ctx* c, const T* pts, int64_t n, const A* attrib, int64_t attrib_rows, int attrib_cols, const double* voxel_size3,  \
                                    const double* min_bound3, const double* max_bound3, int min_points_per_voxel, T* out_v, A* out_attrib, int64_t* out_count,  \
                                    unsigned flags, void* stream) {                                                                                  \
-    DeviceGuard dg(c ? c->device : -1);                                                                                                             \
-    return voxel_downsample_impl<T, A>(c, pts, n, attrib, attrib_rows, attrib_cols, voxel_size3, min_bound3, max_bound3, min_points_per_voxel, out_v, out_attrib, out_count, flags, stream); }
+    CallGuard dg(c);                                                                                                             \
+    return abi_rc(voxel_downsample_impl<T, A>(c, pts, n, attrib, attrib_rows, attrib_cols, voxel_size3, min_bound3, max_bound3, min_points_per_voxel, out_v, out_attrib, out_count, flags, stream)); }
 PCU_VOXEL(f32_f32, float, float) PCU_VOXEL(f32_f64, float, double) PCU_VOXEL(f64_f32, double, float) PCU_VOXEL(f64_f64, double, double)
 #undef PCU_VOXEL
 int pcu_hip_dedup_f32(pcu_hip_ctx* c, const float* pts, int64_t n, double epsilon, float* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return dedup_impl<float>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
+    CallGuard dg(c); return abi_rc(dedup_impl<float>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream)); }
 int pcu_hip_dedup_f64(pcu_hip_ctx* c, const double* pts, int64_t n, double epsilon, double* out_pts, int32_t* out_svi, int32_t* out_svj, int64_t* out_count, unsigned flags, void* stream) {
-    DeviceGuard dg(c ? c->device : -1); return dedup_impl<double>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream); }
+    CallGuard dg(c); return abi_rc(dedup_impl<double>(c, pts, n, epsilon, out_pts, out_svi, out_svj, out_count, flags, stream)); }
 
 #define PCU_SINK(SUF, T)                                                                                                                             \
 int pcu_hip_pairwise_##SUF(pcu_hip_ctx* c, const T* a, const T* b, int64_t nb, int64_t m, int64_t n, int64_t d, double p_norm, T* out, unsigned flags, void* stream) {  \
-    DeviceGuard dg(c ? c->device : -1); return pairwise_impl<T>(c, a, b, nb, m, n, d, p_norm, out, flags, stream); }                                 \
+    CallGuard dg(c); return abi_rc(pairwise_impl<T>(c, a, b, nb, m, n, d, p_norm, out, flags, stream)); }                                 \
 int pcu_hip_sinkhorn_##SUF(pcu_hip_ctx* c, const T* a, const T* b, const T* M, int64_t nb, int64_t m, int64_t n, double eps, int max_iters, double stop_thresh,  \
                            T* out_P, int* out_iters, unsigned flags, void* stream) {                                                                 \
-    DeviceGuard dg(c ? c->device : -1); return sinkhorn_impl<T>(c, a, b, M, nb, m, n, eps, max_iters, stop_thresh, out_P, out_iters, flags, stream); } \
+    CallGuard dg(c); return abi_rc(sinkhorn_impl<T>(c, a, b, M, nb, m, n, eps, max_iters, stop_thresh, out_P, out_iters, flags, stream)); } \
 int pcu_hip_dot_##SUF(pcu_hip_ctx* c, const T* x, const T* y, int64_t count, double* out, unsigned flags, void* stream) {                            \
-    DeviceGuard dg(c ? c->device : -1); return dot_impl<T>(c, x, y, count, out, flags, stream); }
+    CallGuard dg(c); return abi_rc(dot_impl<T>(c, x, y, count, out, flags, stream)); }
 PCU_SINK(f32, float) PCU_SINK(f64, double)
 #undef PCU_SINK
 
 int pcu_hip_ctx_set_batch_lanes(pcu_hip_ctx* c, int lanes) { if (!c) return fail(PCU_HIP_ERR_INVALID, "null context"); c->n_lanes_wanted = lanes > 0 ? lanes : 4; return 0; }
 
-int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
-int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { DeviceGuard dg(c ? c->device : -1); return debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes); }
+int pcu_hip_debug_kd_tree_f32(pcu_hip_ctx* c, const float* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { CallGuard dg(c); return abi_rc(debug_kd<float>(c, pts, n, leaf_max, out_vacc, out_nnodes)); }
+int pcu_hip_debug_kd_tree_f64(pcu_hip_ctx* c, const double* pts, int64_t n, int leaf_max, int64_t* out_vacc, int64_t* out_nnodes) { CallGuard dg(c); return abi_rc(debug_kd<double>(c, pts, n, leaf_max, out_vacc, out_nnodes)); }
 
 int pcu_hip_index_create_f32(pcu_hip_ctx* c, const float* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
-    DeviceGuard dg(c ? c->device : -1);
-    return index_create_impl<float>(c, r, nr, k_hint, flags, stream, out);
+    CallGuard dg(c);
+    return abi_rc(index_create_impl<float>(c, r, nr, k_hint, flags, stream, out));
 }
 int pcu_hip_index_create_f64(pcu_hip_ctx* c, const double* r, int64_t nr, int k_hint, unsigned flags, void* stream, pcu_hip_index** out) {
-    DeviceGuard dg(c ? c->device : -1);
-    return index_create_impl<double>(c, r, nr, k_hint, flags, stream, out);
+    CallGuard dg(c);
+    return abi_rc(index_create_impl<double>(c, r, nr, k_hint, flags, stream, out));
 }
 int pcu_hip_index_knn_f32(pcu_hip_ctx* c, const pcu_hip_index* ix, const float* q, int64_t nq, int k, int max_leaf, float* od, int64_t* oi,
                           unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
-    DeviceGuard dg(c ? c->device : -1);
-    return knn_impl<float>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
+    CallGuard dg(c);
+    return abi_rc(knn_impl<float>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix));
 }
 int pcu_hip_index_knn_f64(pcu_hip_ctx* c, const pcu_hip_index* ix, const double* q, int64_t nq, int k, int max_leaf, double* od, int64_t* oi,
                           unsigned flags, void* stream, pcu_hip_stats* st) {
     if (!ix) return fail(PCU_HIP_ERR_INVALID, "null index");
-    DeviceGuard dg(c ? c->device : -1);
-    return knn_impl<double>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix);
+    CallGuard dg(c);
+    return abi_rc(knn_impl<double>(c, q, nq, nullptr, ix->n, k, max_leaf, od, oi, flags, stream, st, ix));
 }
 int64_t pcu_hip_index_size(const pcu_hip_index* ix) { return ix ? ix->n : 0; }
 void pcu_hip_index_destroy(pcu_hip_index* ix) {

@@ -135,3 +135,52 @@ def test_sigint_handler_chains_to_the_interpreters():
         "print(ok)\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("[True, True, True, 'ignored']"), (r.stdout, r.stderr[-2000:])
+
+
+def test_sigint_rule_is_the_references():
+    """The reference abandons a call only if the interpreter's SIGINT handler RAISES (`if (PyErr_CheckSignals() != 0) throw`,
+    /root/reference/src/point_cloud_distance.cpp:60-75): (i) the library records who asked for the cancellation; (ii) a handler installed with
+    signal.signal() AFTER the library's (which replaces it) is chained again by the next compute call; (iii) _lib._after_call -- the errcheck of
+    every compute entry point -- re-issues a SIGINT-abandoned call when the handler only took note, and lets a raising handler's exception
+    through; (iv) pcu.cancel() always ends the call. No GPU needed (the compute call used for (ii) fails on its null context, after its guard)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, os, signal, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from point_cloud_utils_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "L.pcu_hip_cancel(); assert L.pcu_hip_cancel_source() == _lib.CANCEL_BY_REQUEST\n"
+        "noted = []\n"
+        "signal.signal(signal.SIGINT, lambda s, f: noted.append(s))          # replaces the library's handler\n"
+        "os.kill(os.getpid(), signal.SIGINT); time.sleep(0.05)\n"
+        "assert noted == [signal.SIGINT] and L.pcu_hip_cancel_source() == _lib.CANCEL_BY_REQUEST      # (ours is gone: nothing recorded)\n"
+        "rc = L.pcu_hip_knn_f32(None, None, 0, None, 0, 1, 10, None, None, 0, None, None)\n"
+        "assert rc == _lib.ERR_INVALID, rc                                    # null context; the guard has re-armed the chain\n"
+        "os.kill(os.getpid(), signal.SIGINT); time.sleep(0.05)\n"
+        "assert noted == [signal.SIGINT] * 2 and L.pcu_hip_cancel_source() == _lib.CANCEL_BY_SIGINT\n"
+        "calls = []\n"
+        "def fake(*a):\n"
+        "    calls.append(a); return 0\n"
+        "os.kill(os.getpid(), signal.SIGINT)\n"
+        "assert _lib._after_call(_lib.ERR_CANCELLED, fake, (1, 2)) == 0 and calls == [(1, 2)]     # a handler that takes note: the call runs again\n"
+        "assert _lib._after_call(_lib.ERR_INVALID, fake, (3,)) == _lib.ERR_INVALID and len(calls) == 1\n"
+        "signal.signal(signal.SIGINT, signal.default_int_handler)\n"
+        "L.pcu_hip_knn_f32(None, None, 0, None, 0, 1, 10, None, None, 0, None, None)\n"
+        "try:\n"
+        "    signal.pthread_sigmask(signal.SIG_BLOCK, [signal.SIGINT]); os.kill(os.getpid(), signal.SIGINT)\n"
+        "    signal.pthread_sigmask(signal.SIG_UNBLOCK, [signal.SIGINT])\n"
+        "    _lib._after_call(_lib.ERR_CANCELLED, fake, (4,)); time.sleep(1.0); raised = False\n"
+        "except KeyboardInterrupt:\n"
+        "    raised = True\n"
+        "assert raised and len(calls) == 1\n"
+        "L.pcu_hip_cancel()\n"
+        "assert _lib._after_call(_lib.ERR_CANCELLED, fake, (5,)) == _lib.ERR_CANCELLED and len(calls) == 1   # pcu.cancel(): never re-issued\n"
+        "try:\n"
+        "    _lib.check(_lib.ERR_CANCELLED); ok = False\n"
+        "except KeyboardInterrupt:\n"
+        "    ok = True\n"
+        "assert ok\n"
+        "print('rule ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("rule ok"), (r.stdout, r.stderr[-3000:])

@@ -65,6 +65,30 @@ def test_normals_knn_vs_oracle(pcu, oracle_kind, dtype, k):
     _check(both, nrm[a], both, nrm0[b], gap[b], signed=True)
 
 
+@pytest.mark.parametrize("shape", ["ribbon", "flat"])
+def test_normals_thin_neighbourhoods_f64(pcu, oracle_kind, shape):
+    """Near-degenerate fits in float64 (round-5 advice): a ribbon (extent 1 x 1e-7 x 1e-11; a 12-point neighbourhood spans ~6e-4 of it: the two smallest eigenvalues
+    of the trace-1 covariance are ~1e-9 and ~1e-16, the eigenvector error of a Jacobi solver is off-diagonal mass / gap) and a sheet with 1e-9 of noise.
+    The numpy SVD of the offset matrix resolves both directions; the GPU's eigen-solver of A^T A must agree to 1e-10 in 1 - |n . n0|
+    wherever the smallest direction is separated at all (relative singular gap > 1e-7; src/point_cloud_normals.cpp:155-160)."""
+    rng = np.random.default_rng(17)
+    n, k = 20000, 12
+    if shape == "ribbon":
+        p = np.stack([rng.random(n), 1e-7 * rng.random(n), 1e-11 * rng.normal(size=n)], 1)
+    else:
+        p = np.stack([rng.random(n), rng.random(n), 1e-9 * rng.normal(size=n)], 1)
+    rot = np.linalg.qr(rng.normal(size=(3, 3)))[0]              # (not axis-aligned: the rotations have work to do)
+    p = np.ascontiguousarray(p @ rot.T)
+    idx, nrm = pcu.estimate_point_cloud_normals_knn(p, k)
+    idx0, nrm0, gap = oracle.normals_knn(p, k, kind=oracle_kind)
+    assert np.array_equal(idx, idx0)
+    good = gap > 1e-7
+    assert good.mean() > 0.9, good.mean()
+    dot = np.abs(np.einsum("ij,ij->i", nrm, nrm0))
+    assert np.all(1.0 - dot[good] <= 1e-10), float((1.0 - dot[good]).max())
+    assert np.allclose(np.abs(nrm @ rot[:, 2]), 1.0, atol=1e-3 if shape == "ribbon" else 1e-6)       # and it is the geometric normal
+
+
 def test_normals_knn_edge_cases(pcu):
     p = cloud(5, 50, np.float64)
     idx, nrm = pcu.estimate_point_cloud_normals_knn(p, 60)           # more neighbours than points: every point is dropped

@@ -8,7 +8,8 @@ that round's kernels. This file moves the volume in front of the driver:
     before, only offset 1000 and one offset-3 case were covered), f32 and f64, k in {1, 16};
   * lane-pass near ties: dataset point pairs constructed to lie 1 .. 8 ulps apart in d2 from grid-interior queries, the regime in which a
     minimum-taking search and nanoflann's incremental bound could disagree (DESIGN 2 "Near ties").
-Seeds derive from ROUND (bump it per round: new cases each round) or PCU_SWEEP_SEED. Sizes are chosen so that the whole file runs in about two
+Seeds derive from ROUND -- one more than the newest BENCH_rNN.json the driver has left at the repo root, so every round's run draws cases no
+earlier round ran, without anybody editing this file -- or from PCU_SWEEP_SEED. Sizes are chosen so that the whole file runs in about two
 minutes, the CPU reference included; every GPU call also carries a generous time bound (a pathological path is a finding too)."""
 import os
 import time
@@ -20,7 +21,17 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 
-ROUND = 5
+
+
+def _round_number():
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = [int(m.group(1)) for f in glob.glob(os.path.join(root, "BENCH_r*.json")) for m in [re.search(r"BENCH_r(\d+)\.json$", f)] if m]
+    return max(done, default=0) + 1
+
+
+ROUND = _round_number()
 SEED = int(os.environ.get("PCU_SWEEP_SEED", 1000 * ROUND + 7))
 N_GENERAL = 160
 DISTS = ["uniform", "plane", "line", "clusters", "dups", "lattice", "offset", "aniso", "sphere", "mixed"]
