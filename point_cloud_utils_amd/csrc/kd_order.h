@@ -1063,6 +1063,7 @@ struct KdSearchArgs {
     int k, squared, row_out;
     T* out_d; long long* out_i;
     void* stack; int stack_cap;         // per work item: stack_cap frames (tree depth + 2) in global memory
+    const unsigned* cancel_word = nullptr; unsigned cancel_gen = 0;       // pcu_types.h: cancel_seen (looked at every 1024 traversal steps)
     int t0 = 0;                         // k_kd_search: first query of this launch (long query lists are enqueued in pieces, pcu_hip.hip: kd_search_launch)
     int* error_flag;
     // whole-cloud mode (k beyond the grid search's capacity, kd_search<T, true>): queries are the raw (nq, 3) rows, every block
@@ -1110,7 +1111,9 @@ __device__ __forceinline__ void kd_search_one(const KdSearchArgs<T>& a, const in
     int sp = 0;
     Frame f; f.node = 0; f.stage = 0; f.mindistsq = distsq; f.other = 0; f.idx = 0; f.cut = 0; f.dst = 0;
     // `f` is the frame on top (kept in registers, wave-uniform); st[] holds the frames below it.
+    unsigned steps = 0;
     while (true) {
+        if ((++steps & (BIG ? 63u : 1023u)) == 0u && cancel_seen(a.cancel_word, a.cancel_gen)) return;      // the call has been abandoned: so is this traversal (BIG: a step can be a k-wide insertion)
         const KdNode<T>& nd = a.nodes[f.node];
         bool pop = false;
         if (f.stage == 0) {
@@ -1235,7 +1238,7 @@ __global__ __launch_bounds__(64) void k_kd_search_all(const KdSearchArgs<T> a) {
     for (int t = blockIdx.x; t < a.nq_raw; t += gridDim.x) {
         Pt4<T> q; q.x = a.qraw[3 * (size_t)t]; q.y = a.qraw[3 * (size_t)t + 1]; q.z = a.qraw[3 * (size_t)t + 2]; q.idx = t;
         kd_search_one<T, true>(a, t, (int)blockIdx.x, q, (size_t)t, rd, ri, s_dists, s_vec);
-        if (*(volatile int*)a.error_flag) return;
+        if (*(volatile int*)a.error_flag || cancel_seen(a.cancel_word, a.cancel_gen)) return;
         __syncthreads();
     }
 }

@@ -49,7 +49,7 @@ static int fail(int code, const char* fmt, ...) {
     g_fail_code = code;
     return code;
 }
-static inline int abi_rc(int rc) { return rc < 0 && g_fail_code < 0 ? g_fail_code : rc; }
+static int abi_rc(int rc);
 #define HIP_TRY(x)                                                                              \
     do { hipError_t e_ = (x); if (e_ != hipSuccess)                                             \
         return fail(PCU_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -69,8 +69,18 @@ static inline int abi_rc(int rc) { return rc < 0 && g_fail_code < 0 ? g_fail_cod
 // of a batch call, or a context destroyed by another thread or the garbage collector, cannot swallow a request. Contexts reset their cross-call
 // device state (the "no memset" fill words, the speculative tree top) when they see that a call was abandoned since their last one
 // (g_cancel_epoch).
-static std::atomic<unsigned> g_cancel_gen{0};          // number of requests so far
 static std::atomic<int> g_cancel_source{0};            // who made the last one: PCU_HIP_CANCEL_BY_REQUEST / PCU_HIP_CANCEL_BY_SIGINT
+static std::atomic<unsigned> g_cancel_gen{0};          // number of requests so far
+// ... and its copy in pinned, device-visible host memory (allocated with the first context): the kernels that can run for tens or hundreds of
+// milliseconds -- the tie-order / big-k traversals, the wave-per-query pass -- look at it every ~1000 steps and return when it has moved past
+// their call's value (pcu_types.h: cancel_seen), so that ONE long call is abandoned within milliseconds, not at its next host phase. The copy is
+// written after the counter, and a kernel only reacts to "newer than my call": whenever a kernel has bailed out, the host's own test is true.
+static std::atomic<unsigned*> g_cancel_mirror{nullptr};
+static inline void cancel_request(int source) {
+    g_cancel_source.store(source, std::memory_order_relaxed);
+    const unsigned g = g_cancel_gen.fetch_add(1, std::memory_order_acq_rel) + 1u;
+    if (unsigned* m = g_cancel_mirror.load(std::memory_order_acquire)) __atomic_store_n(m, g, __ATOMIC_RELEASE);
+}
 static thread_local unsigned t_call_gen = 0;           // g_cancel_gen when this thread's current call began
 static std::atomic<unsigned> g_cancel_epoch{0};
 static struct sigaction g_prev_sigint;
@@ -81,8 +91,7 @@ static void pcu_on_sigint(int sig, siginfo_t* info, void* uc) {
     if (g_in_sigint.exchange(1)) return;
     const struct sigaction prev = g_prev_sigint;
     if ((prev.sa_flags & SA_SIGINFO) || prev.sa_handler != SIG_IGN) {                                 // the host ignores SIGINT: so do the calls
-        g_cancel_source.store(PCU_HIP_CANCEL_BY_SIGINT, std::memory_order_relaxed);
-        g_cancel_gen.fetch_add(1, std::memory_order_relaxed);
+        cancel_request(PCU_HIP_CANCEL_BY_SIGINT);
         if (prev.sa_flags & SA_SIGINFO) { if (prev.sa_sigaction && prev.sa_sigaction != pcu_on_sigint) prev.sa_sigaction(sig, info, uc); }
         else if (prev.sa_handler != SIG_DFL && prev.sa_handler) prev.sa_handler(sig);
         else if (prev.sa_handler == SIG_DFL) { g_in_sigint.store(0); signal(SIGINT, SIG_DFL); raise(SIGINT); return; }   // no handler before ours: the default action
@@ -120,13 +129,20 @@ static int cancelled(hipStream_t s) {
     return fail(PCU_HIP_ERR_CANCELLED, "cancelled (pcu_hip_cancel / SIGINT) while waiting for the GPU");
 }
 static inline bool cancel_requested() { return g_cancel_gen.load(std::memory_order_relaxed) != t_call_gen; }
+// What a compute entry point returns: the code its failure was recorded with; and a call that ran to its end while a request was pending --
+// its last kernels may have bailed out -- is an abandoned call, whatever its host phases saw.
+static int abi_rc(int rc) {
+    if (rc < 0) return g_fail_code < 0 ? g_fail_code : rc;
+    if (rc == 0 && cancel_requested()) return cancelled(nullptr);
+    return rc;
+}
 // hipStreamSynchronize as a bounded poll: tight for the first 2 ms (short calls keep their latency), then 50 us naps.
 static int wait_stream(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     bool nap = false;
     for (unsigned it = 0;; ++it) {
         const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) return 0;
+        if (e == hipSuccess) return cancel_requested() ? cancelled(s) : 0;       // (a kernel may have bailed out on the request: its results do not count)
         if (e != hipErrorNotReady) return fail(PCU_HIP_ERR_RUNTIME, "hipStreamQuery failed: %s", hipGetErrorString(e));
         if (cancel_requested()) return cancelled(s);
         if (!nap && (it & 0x3f) == 0x3f && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) nap = true;
@@ -138,7 +154,7 @@ static int wait_stream(hipStream_t s) {
 static int wait_event(hipEvent_t ev, hipStream_t s) {
     for (unsigned it = 0;; ++it) {
         const hipError_t e = hipEventQuery(ev);
-        if (e == hipSuccess) return 0;
+        if (e == hipSuccess) return cancel_requested() ? cancelled(s) : 0;
         if (e != hipErrorNotReady) return fail(PCU_HIP_ERR_RUNTIME, "hipEventQuery failed: %s", hipGetErrorString(e));
         if (cancel_requested()) return cancelled(s);
         if (it > 64) { struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
@@ -828,6 +844,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.fuse = j.fuse; a.f_sum = j.f_sum; a.f_max_v = j.f_max_v; a.f_max_k = j.f_max_k;
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
     a.bad_r = j.bad_r; a.bad_q = j.bad_q; a.escalate = 0;
+    a.cancel_word = g_cancel_mirror.load(std::memory_order_relaxed); a.cancel_gen = t_call_gen;
     return a;
 }
 
@@ -1275,6 +1292,7 @@ static int tie_order_resolve(pcu_hip_ctx* c, Arena& ar, hipStream_t s, SearchJob
         a.E = b.E; a.nodes = b.nodes; a.qsorted = j.qidx.sorted; a.qlist = j.sc.tt; a.qcount_dev = j.sc.counters + C_TT;
         a.k = j.k; a.squared = j.squared ? 1 : 0; a.row_out = j.row_out ? 1 : 0; a.out_d = j.out_d; a.out_i = j.out_i; a.error_flag = err;
         a.qraw = nullptr; a.nq_raw = 0; a.rs_d = nullptr; a.rs_i = nullptr;
+        a.cancel_word = g_cancel_mirror.load(std::memory_order_relaxed); a.cancel_gen = t_call_gen;
         KdFrame<T>* frames = nullptr;
         a.stack_cap = levels + 2;
         if (aalloc(ar, &frames, (size_t)n_tt * a.stack_cap)) return -1;
@@ -1628,6 +1646,7 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
         a.E = b.E; a.nodes = b.nodes; a.qsorted = nullptr; a.qlist = nullptr; a.qcount_dev = nullptr;
         a.k = k; a.squared = squared ? 1 : 0; a.row_out = 1; a.out_d = dd; a.out_i = di; a.error_flag = err;
         a.qraw = dq; a.nq_raw = (int)nq; a.rs_d = nullptr; a.rs_i = nullptr;
+        a.cancel_word = g_cancel_mirror.load(std::memory_order_relaxed); a.cancel_gen = t_call_gen;
         if (!rs_lds && ((rc = aalloc(ar, &a.rs_d, (size_t)grid * k)) || (rc = aalloc(ar, &a.rs_i, (size_t)grid * k)))) break;
         KdFrame<T>* frames = nullptr;
         a.stack_cap = levels + 2;
@@ -1941,7 +1960,7 @@ static int wait_result_block(pcu_hip_ctx* c, hipStream_t s) {
         volatile int* flag = c->h_pinned + 63;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 0;; ++it) {
-            if ((unsigned)*flag == c->seq) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+            if ((unsigned)*flag == c->seq) { std::atomic_thread_fence(std::memory_order_acquire); return cancel_requested() ? cancelled(s) : 0; }
             if ((it & 0x3ff) == 0x3ff) {
                 if (cancel_requested()) return cancelled(s);
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // long call or fault: poll the stream instead
@@ -2628,7 +2647,7 @@ int pcu_hip_device_count(void) {
     return n;
 }
 
-void pcu_hip_cancel(void) { g_cancel_source.store(PCU_HIP_CANCEL_BY_REQUEST, std::memory_order_relaxed); g_cancel_gen.fetch_add(1, std::memory_order_relaxed); }
+void pcu_hip_cancel(void) { cancel_request(PCU_HIP_CANCEL_BY_REQUEST); }
 int pcu_hip_cancel_source(void) { return g_cancel_source.load(std::memory_order_relaxed); }
 int pcu_hip_watch_sigint(int enable) {
     if (enable && !g_sigint_watched.exchange(1)) {
@@ -2646,6 +2665,14 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     if (n <= 0) return fail(PCU_HIP_ERR_NO_DEVICE, "no HIP device visible: the gfx950 path has no CPU fallback");
     if (device < 0 || device >= n) return fail(PCU_HIP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
     DeviceGuard dg(device);
+    if (!g_cancel_mirror.load(std::memory_order_acquire)) {
+        unsigned* m = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&m, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        *m = g_cancel_gen.load(std::memory_order_relaxed);
+        unsigned* expected = nullptr;
+        if (!g_cancel_mirror.compare_exchange_strong(expected, m)) (void)hipHostFree(m);        // (another thread's context was first)
+        else __atomic_store_n(m, g_cancel_gen.load(std::memory_order_acquire), __ATOMIC_RELEASE);
+    }
     pcu_hip_ctx* c = new pcu_hip_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));

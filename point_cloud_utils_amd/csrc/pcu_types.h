@@ -47,6 +47,13 @@ template <typename T> __device__ __forceinline__ void put_sentinels(Pt4<T>* sort
 }
 constexpr size_t sorted_records_bytes(size_t n, size_t rec_bytes, size_t scalar_bytes) { return (n + 8) * rec_bytes + (PCU_FLAT_XYZ ? (n + 8) * (3 * scalar_bytes + 4) : 0); }
 
+// Cancellation inside long-running kernels (pcu_hip.hip: g_cancel_mirror): `word` is a pinned host word holding the process's request counter,
+// `gen` its value when the kernel's call began. True once a request NEWER than the call has been filed. One uncached system-scope load (a PCIe
+// round trip): callers look every ~1000 steps, wave-uniformly.
+__device__ __forceinline__ bool cancel_seen(const unsigned* word, unsigned gen) {
+    return word != nullptr && (int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - gen) > 0;
+}
+
 template <typename T> struct Limits;
 template <> struct Limits<float>  { static constexpr float  max_v = FLT_MAX; static constexpr float  eps = FLT_EPSILON; };
 template <> struct Limits<double> { static constexpr double max_v = DBL_MAX; static constexpr double eps = DBL_EPSILON; };

@@ -81,6 +81,7 @@ struct SearchArgs {
     int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
                                     // slots instead of overwriting them
     int escalate;                   // wave-per-query passes: finish every query inside the launch (box round, then the ball round: k_search_wave)
+    const unsigned* cancel_word; unsigned cancel_gen;      // pcu_types.h: cancel_seen (the wave-per-query pass looks between its work items)
     int bad_r, bad_q;               // GridParams::nonfinite flags (grid.h: kNf*) of the dataset / of the query cloud that this operator rejects:
                                     // the passes give up at once and raise bit 2 of the large-bucket flag word (-> ValueError on the host)
 };
@@ -1299,6 +1300,7 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = hl0; total0 = 0; }
     if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = hl1; total1 = 0; }
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
+        if (wg != wave && cancel_seen(a0.cancel_word, a0.cancel_gen)) break;       // (from a wave's second work item on: short launches never look)
         const bool job1 = wg >= total0;
         const SearchArgs<T>& a = job1 ? a1 : a0;
         const int w = job1 ? wg - total0 : wg;
