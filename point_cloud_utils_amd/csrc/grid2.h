@@ -75,6 +75,12 @@ struct Build2Side {
     unsigned long long* zero_next; int n_zero_next;       // the other set of fill words, zeroed for the context's next build (side 0 only)
     unsigned* zero2; int n_zero2;   // the call's result block (side 0 only)
     long long* prof;                // diagnostics (PCU_HIP_PROF_BUILD2): per-stage time of every block's thread 0, summed; 100 MHz ticks
+    // SHARED GRID (round 6; two-sided calls between clouds of comparable size): both clouds of the call are laid over ONE grid -- same origin,
+    // cell edge and cell counts -- so that a query's cell in its own cloud's order IS its cell in the dataset's grid and a block of consecutive
+    // queries needs a compact box of dataset rows (search_brick.h stages that box in LDS). The layout then comes from 512 samples of EACH cloud,
+    // read in the same order by the blocks of both sides (identical arithmetic on identical inputs: identical grids), for n_layout = the larger
+    // cloud's size. spts1 == nullptr: the cloud's own grid from its own 1024 samples, as before.
+    const T* spts0; int sn0; const T* spts1; int sn1; int n_layout;
 };
 
 // A column of per-thread values (NT threads) folded by one wave: lane l takes the values of threads l, l + 64, ...; the result is valid in lane 63.
@@ -121,11 +127,12 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
     const P3* const pts3 = reinterpret_cast<const P3*>(a.pts);
     // ---- grid layout from the sample (every block the same). The sample is requested BEFORE the block's own points: loads return in order, so
     // the layout waits for the sample only and runs while the points are still in flight.
-    const bool all = n < kPrepSamples;            // a cloud smaller than the sample: every point
+    const bool shared = a.spts1 != nullptr;       // (both clouds hold >= kPrepSamples points then: the host's rule)
+    const bool all = !shared && n < kPrepSamples; // a cloud smaller than the sample: every point
     const int S = all ? n : kPrepSamples;
     static_assert(kPrepSamples == kBkThreads, "one sample per thread");
     P3 sv, pv;
-    {
+    if (!shared) {
         const int j = min(tid, S - 1);            // sample j: one point of the slice [j n / S, (j + 1) n / S), position hashed
         size_t i = (size_t)j;
         if (!all) {
@@ -134,6 +141,13 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
             i = (size_t)b0 + (size_t)(((unsigned long long)hash32((unsigned)j) * (unsigned long long)(unsigned)(b1 - b0)) >> 32);
         }
         sv = pts3[i]; pv = pts3[0];
+    } else {                                      // threads 0..511: the call's first cloud, 512..1023: its second -- on BOTH sides
+        const int half = tid >> 9, j = tid & 511;
+        const P3* const src = reinterpret_cast<const P3*>(half ? a.spts1 : a.spts0);
+        const int ns = half ? a.sn1 : a.sn0;
+        const unsigned long long b0 = ((unsigned long long)j * (unsigned long long)ns) >> 9, b1 = ((unsigned long long)(j + 1) * (unsigned long long)ns) >> 9;
+        const size_t i = (size_t)b0 + (size_t)(((unsigned long long)hash32((unsigned)tid) * (unsigned long long)(unsigned)(b1 - b0)) >> 32);
+        sv = src[i]; pv = reinterpret_cast<const P3*>(a.spts0)[0];
     }
     T px[PTS], py[PTS], pz[PTS];
 #pragma unroll
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
                     }
                 }
             }
-            grid_layout<T>(&s_gp, rlo, rhi, n, a.occupancy, a.max_cells, a.h_want);
+            grid_layout<T>(&s_gp, rlo, rhi, shared ? a.n_layout : n, a.occupancy, a.max_cells, a.h_want);
             if (bid == 0) {             // the side's first block publishes the geometry for the kernels that follow
                 GridParams<T>& o = *a.gp;
                 for (int j = 0; j < 3; ++j) { o.gmin[j] = s_gp.gmin[j]; o.gmax[j] = s_gp.gmax[j]; o.slack[j] = s_gp.slack[j]; o.G[j] = s_gp.G[j]; o.org[j] = s_gp.org[j]; }

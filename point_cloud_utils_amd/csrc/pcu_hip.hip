@@ -25,6 +25,7 @@
 #include "grid2.h"
 #include "reduce.h"
 #include "search.h"
+#include "search_brick.h"
 namespace pcu {          // the k > 1 search kernels are compiled in search_kernels.hip (second translation unit, built in parallel)
 #define PCU_SEARCH_INST extern template
 #include "search_inst.h"
@@ -236,6 +237,8 @@ struct pcu_hip_ctx {
                                                                  // fill_parity -- left zeroed by its predecessor -- and zeroes the other one for its successor
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
+    bool brick_off = false;                   // sticky: a staged k = 1 pass of this context (search_brick.h) fell back to global scans in more than a quarter of its
+                                              // blocks (surfaces, clusters: short uneven rows): its fused calls take k_search1_flat on per-cloud grids again
     unsigned cancel_epoch = 0;                // g_cancel_epoch at this context's last call (ctx_begin: reset of the cross-call device state after an abandoned call)
     std::vector<pcu_hip_ctx*> lanes; int n_lanes_wanted = 4;   // (262k-point pairs, round 4, us per pair at 1 / 2 / 3 / 4 / 5 / 6 / 8 lanes: 83 / 51 / 43 / 41 / 47 / 44 / 41 -- scratch/lanes.py; the host is the limit from 3 on)
     hipEvent_t batch_ev = nullptr;
@@ -385,6 +388,8 @@ struct GridIndex {
     bool lean = false;                    // the Pt4 records of `sorted` are not written (grid2.h: fused k = 1 calls read the coordinate + row-id streams only);
                                           // make_pt4() fills them in when some other kernel needs them
     const T* src = nullptr; double occ_built = 0.0;       // what the index was built from (rebuild after an overflow)
+    bool shared_grid = false;             // asked for: this cloud and its partner of a two-sided call are laid over ONE grid (grid2.h: Build2Side::spts1); allocated for
+                                          // the larger cloud's plan. Cleared by a build that did not take the second-form one-pass path
 };
 
 static int max_cells_for(int64_t n, double occ) {
@@ -426,9 +431,11 @@ static size_t index_bytes(int64_t n, double occ) {
     return b;
 }
 template <typename T>
-static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool want_pos = false, bool allow_bucketed = true, bool one_pass = false) {
-    g.n = (int)n; g.max_cells = max_cells_for(n, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
-    g.bucketed = allow_bucketed && bucket_plan(n, occ, &g.shift, &g.nb_max);
+static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool want_pos = false, bool allow_bucketed = true, bool one_pass = false, int64_t n_plan = 0) {
+    // (n_plan: the cell / bucket plan of a larger cloud -- the partner this cloud shares its grid with, see GridIndex::shared_grid)
+    const int64_t np = n_plan > n ? n_plan : n;
+    g.n = (int)n; g.max_cells = max_cells_for(np, occ); g.scan_blocks = g.max_cells / kScanChunk + 1;
+    g.bucketed = allow_bucketed && bucket_plan(np, occ, &g.shift, &g.nb_max);
     if (aalloc(a, &g.gp, 1)) return -1;
     // (cell_start sits 256 bytes INTO its block: the k = 1 / k > 1 lane kernels read the row table of a query in the first cell of the first row
     // from one word BEFORE cell_start (search.h: "uniform four-word tables"; the word is never used, but its address must be mapped -- also when
@@ -504,9 +511,18 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         auto side = [&](const GridIndex<T>& g, const T* p, double occ, int k) {
             return Build2Side<T>{p, g.n, g.gp, g.shift, occ, g.max_cells, g.h_want, fw + (size_t)k * kStagedMaxBuckets, fw + 2 * kStagedMaxBuckets + k,
                                  g.tmp, kLargeBucket, g.xpartial, (g.n + bpts - 1) / bpts, g.cell_start, g.sorted, g.pos_of, g.lean ? 0 : 1, g.n_large,
-                                 k == 0 ? fw_next : nullptr, k == 0 ? kFillWords : 0, k == 0 ? (unsigned*)zero2 : nullptr, k == 0 ? n_zero2 : 0, nullptr};
+                                 k == 0 ? fw_next : nullptr, k == 0 ? kFillWords : 0, k == 0 ? (unsigned*)zero2 : nullptr, k == 0 ? n_zero2 : 0, nullptr,
+                                 p, g.n, nullptr, 0, g.n};
         };
         Build2Side<T> s0 = side(a, pa, occa, 0), s1 = b ? side(*b, pb, occb, 1) : s0;
+        // one grid for both clouds (GridIndex::shared_grid): same plan (index_alloc's n_plan), same occupancy, both at least a sample large
+        const bool shared = b && a.shared_grid && b->shared_grid && occa == occb && a.max_cells == b->max_cells && a.shift == b->shift && a.nb_max == b->nb_max &&
+                            a.h_want == b->h_want && a.n >= kPrepSamples && b->n >= kPrepSamples;
+        if (b) a.shared_grid = b->shared_grid = shared; else a.shared_grid = false;
+        if (shared) {
+            s0.spts0 = s1.spts0 = pa; s0.sn0 = s1.sn0 = a.n; s0.spts1 = s1.spts1 = pb; s0.sn1 = s1.sn1 = b->n;
+            s0.n_layout = s1.n_layout = std::max(a.n, b->n);
+        }
         const int c0 = s0.n_xpart, c1 = b ? s1.n_xpart : 0;
         static const bool do_prof2 = getenv("PCU_HIP_PROF_BUILD2") != nullptr;
         static long long* prof2 = nullptr;
@@ -541,6 +557,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         return 0;
     }
     a.lean = false; if (b) b->lean = false;            // (every other build writes the Pt4 records)
+    a.shared_grid = false; if (b) b->shared_grid = false;      // (... and lays every cloud over its own grid)
     {
         const BboxSide<T> s0{pa, a.n, a.bbox_partial, a.cell_start, a.n_zero, (unsigned*)zero2, n_zero2, a.gp};
         const BboxSide<T> s1 = b ? BboxSide<T>{pb, b->n, b->bbox_partial, b->cell_start, b->n_zero, nullptr, 0, b->gp} : s0;
@@ -711,6 +728,10 @@ static int wave_escalates() { static const bool off = getenv("PCU_HIP_NO_ESCALAT
 static bool use_k1_kernel() { static const bool v = getenv("PCU_HIP_NO_K1") == nullptr; return v; }
 static int grid8(int nwork, int tb) { return (((nwork + tb - 1) / tb) + 7) / 8 * 8; }       // multiple of 8: XCD-aware block map
 
+template <typename T> static void launch_brick(const SearchArgs2<T>&, int, int, hipStream_t) {}
+template <> void launch_brick<float>(const SearchArgs2<float>& p2, int b0, int b1, hipStream_t s) {
+    hipLaunchKernelGGL((k_search1_brick<float, kBrickNT>), dim3(b0 + b1), dim3(kBrickNT), 0, s, p2, b0);
+}
 // Main (lane-per-query) pass of one direction, or -- k = 1 on open indexes -- of both directions of a two-sided call in
 // one launch (a1 / nwork1).
 template <typename T>
@@ -721,8 +742,14 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
     // at 1M / k = 1, profiles/r01_search_kernel_ab.txt; a per-wave work-queue variant of the k = 1 pass, 84-87 vs 82-83 us, profiles/r02_ubench.txt.)
     const int tb = kBlock;
     if (K == 1 && use_k1_kernel() && open_index) {        // k = 1 on an open index: the group-wise flat kernel
-        const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         SearchArgs2<T> p2; p2.a[0] = a; p2.a[1] = a1 ? *a1 : a;
+        if (sizeof(T) == 4 && a.fuse == FUSE_SUM && a.brick && a1 && a1->brick && !a.qlist && !a1->qlist) {       // shared grid: the staged pass (search_brick.h)
+            const int b0 = grid8(nwork, kBrickNT), b1 = grid8(nwork1, kBrickNT);
+            launch_brick<T>(p2, b0, b1, s);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        const int g0 = grid8(nwork, tb), g1 = a1 ? grid8(nwork1, tb) : 0;
         // (An LDS-staged, block-cooperative variant of this pass -- the north-star's tile design -- was measured again in round 4: 243-593 us
         // against 77 us, profiles/r04_flat_tile_ab.txt; removed.)
 #ifndef PCU_FLAT_MINW
@@ -820,6 +847,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     SearchScratch<T> sc;
     // fused epilogue (reduce.h): per-block partials of the k = 1 lane pass instead of result rows
     int fuse = FUSE_NONE; int n_flat = 0;
+    bool brick = false;                         // the lane pass is search_brick.h's staged pass (shared grid, fused sum, float)
     double* f_sum = nullptr; T* f_max_v = nullptr; long long* f_max_k = nullptr;
     unsigned long long* f_limbs = nullptr; double* f_special = nullptr; T* f_wave_v = nullptr; long long* f_wave_k = nullptr;
 };
@@ -845,6 +873,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
     a.bad_r = j.bad_r; a.bad_q = j.bad_q; a.escalate = 0;
     a.cancel_word = g_cancel_mirror.load(std::memory_order_relaxed); a.cancel_gen = t_call_gen;
+    a.brick = j.brick ? 1 : 0; a.n_fallback = j.sc.counters + C_SPARE;
     return a;
 }
 
@@ -1825,9 +1854,16 @@ struct PairState {
     bool wave_pending = false;                          // the fused attempt's wave-per-query pass has not been launched (pair_search_enqueue)
     int* tie_hit = nullptr;
 };
+// ONE grid over both clouds of a two-sided call (grid2.h: Build2Side::spts1; what search_brick.h's staged pass needs): clouds of comparable size
+// indexed at the same occupancy. PCU_HIP_NO_SHARED_GRID=1: every cloud its own grid, as before round 6.
+static bool shared_grid_wanted(const pcu_hip_ctx* c, int64_t nx, int64_t ny, double occ_x, double occ_y) {
+    static const bool off = getenv("PCU_HIP_NO_SHARED_GRID") != nullptr;
+    return !off && !c->brick_off && occ_x == occ_y && std::min(nx, ny) >= kPrepSamples && std::max(nx, ny) <= 2 * std::min(nx, ny);
+}
 template <typename T>
 static size_t pair_bytes(int64_t nx, int64_t ny, double occ_x, double occ_y, bool on_dev) {
-    size_t b = index_bytes<T>(nx, occ_x) + index_bytes<T>(ny, occ_y) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
+    // (index_bytes of the LARGER cloud for both: a shared grid is planned for it, index_alloc's n_plan)
+    size_t b = index_bytes<T>(std::max(nx, ny), occ_x) + index_bytes<T>(std::max(nx, ny), occ_y) + scratch_bytes<T>(nx) + scratch_bytes<T>(ny) +
                align_up((size_t)nx * sizeof(T), 256) + align_up((size_t)ny * sizeof(T), 256) +
                align_up((size_t)nx * 8, 256) + align_up((size_t)ny * 8, 256) +
                6 * align_up((size_t)kRedBlocks * 8, 256) + 8192 +
@@ -1859,6 +1895,10 @@ static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, p
 // deferred next to a heavy cell)? Then run it now, fold again, and wait for that result block.
 template <typename T>
 static int fused_wave_if_needed(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock& host) {
+    if (P.xy.brick) {           // the staged pass's report: blocks that scanned from global memory (search_brick.h)
+        const long long fb = (long long)host.counters[0][C_SPARE] + host.counters[1][C_SPARE], nb = (long long)P.xy.n_flat + P.yx.n_flat;
+        if (4 * fb > nb) c->brick_off = true;
+    }
     if (!P.wave_pending) return 0;
     P.wave_pending = false;
     bool need = false, broken = false;
@@ -1888,7 +1928,10 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     if (stage_in(ar, x, nx, on_dev, s, &P.dx)) return -1;
     if (stage_in(ar, y, ny, on_dev, s, &P.dy)) return -1;
     GridIndex<T> ix, iy;
-    if (index_alloc(ar, ix, nx, occ_x, want_pos_x, true, use_one_pass(c)) || index_alloc(ar, iy, ny, occ_y, want_pos_y, true, use_one_pass(c))) return -1;
+    const bool share = two_sided && shared_grid_wanted(c, nx, ny, occ_x, occ_y);
+    const int64_t n_plan = share ? std::max(nx, ny) : 0;
+    if (index_alloc(ar, ix, nx, occ_x, want_pos_x, true, use_one_pass(c), n_plan) || index_alloc(ar, iy, ny, occ_y, want_pos_y, true, use_one_pass(c), n_plan)) return -1;
+    ix.shared_grid = iy.shared_grid = share;
     ix.src = P.dx; iy.src = P.dy; ix.occ_built = occ_x; iy.occ_built = occ_y;        // (the jobs below hold copies: what a rebuild after a slot overflow starts from)
     if (ix.bucketed && iy.bucketed && ix.one_pass != iy.one_pass) ix.one_pass = iy.one_pass = false;
     P.xy.qidx = ix; P.xy.ridx = iy; P.xy.d_ref_pts = P.dy;
@@ -1944,6 +1987,14 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
     if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c)) return -1;
     P.xy.qidx.lean = P.yx.ridx.lean = ix.lean; P.xy.ridx.lean = P.yx.qidx.lean = iy.lean;      // (the build says what it wrote)
+    P.xy.qidx.shared_grid = P.yx.ridx.shared_grid = ix.shared_grid; P.xy.ridx.shared_grid = P.yx.qidx.shared_grid = iy.shared_grid;
+    {   // shared grid + fused sum + float: the staged lane pass (search_brick.h); its per-block partials follow its block size
+        // (measured: 118 us against k_search1_flat's 60.5 on the same shared grid, profiles/r06_flat_aligned_ab.txt -- OFF unless PCU_HIP_BRICK=1)
+        static const bool brick_env_on = getenv("PCU_HIP_BRICK") && atoi(getenv("PCU_HIP_BRICK")) != 0;
+        const bool brick = sizeof(T) == 4 && P.fuse == FUSE_SUM && two_sided && ix.shared_grid && iy.shared_grid && brick_env_on && !c->brick_off;
+        P.xy.brick = P.yx.brick = brick;
+        if (brick) for (int d = 0; d < 2; ++d) { SearchJob<T>& J = d ? P.yx : P.xy; J.n_flat = grid8(J.qidx.n, kBrickNT); P.tail.nflat[d] = J.n_flat; }
+    }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);
     if (pair_search_enqueue(c, s, P, st)) return -1;

@@ -81,6 +81,8 @@ struct SearchArgs {
     int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
                                     // slots instead of overwriting them
     int escalate;                   // wave-per-query passes: finish every query inside the launch (box round, then the ball round: k_search_wave)
+    int brick;                      // 1: query cloud and dataset share ONE grid and the call takes search_brick.h's staged pass (fused sum, float)
+    int* n_fallback;                // ... whose blocks that did not fit their stage count themselves here (pcu_hip.hip: brick feedback)
     const unsigned* cancel_word; unsigned cancel_gen;      // pcu_types.h: cancel_seen (the wave-per-query pass looks between its work items)
     int bad_r, bad_q;               // GridParams::nonfinite flags (grid.h: kNf*) of the dataset / of the query cloud that this operator rejects:
                                     // the passes give up at once and raise bit 2 of the large-bucket flag word (-> ValueError on the host)

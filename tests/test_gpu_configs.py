@@ -162,7 +162,9 @@ SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINU
             "PCU_HIP_HOST_PROF=1", "PCU_HIP_DEBUG_POISON=255", "PCU_HIP_NO_WAVE_MERGE=1",
             # round 5: k > 1 lane pass without the run list (k_search everywhere), the round-4 small-cloud thresholds (wave-per-query below
             # 16384 queries, atomic build below 32768 points), no SIGINT watch
-            "PCU_HIP_KSEARCH_V1=1", "PCU_HIP_WAVE_ONLY_BELOW=16384", "PCU_HIP_BUCKET_MIN=32768", "PCU_HIP_NO_SIGINT=1"]
+            "PCU_HIP_KSEARCH_V1=1", "PCU_HIP_WAVE_ONLY_BELOW=16384", "PCU_HIP_BUCKET_MIN=32768", "PCU_HIP_NO_SIGINT=1",
+            # round 6: every cloud of a two-sided call on its own grid again; the LDS-staged k = 1 pass over the shared grid (search_brick.h)
+            "PCU_HIP_NO_SHARED_GRID=1", "PCU_HIP_BRICK=1"]
 
 
 @pytest.mark.gpu

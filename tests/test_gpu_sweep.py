@@ -202,6 +202,45 @@ def test_fused_sum_is_the_sum_of_the_rows(pcu, dtype, dq, dr):
             assert abs(got - want) <= 1e-10 * want + 1e-300, (dq, dr, got, want)
 
 
+def test_staged_pass_on_the_shared_grid_sums_the_same_rows(pcu, tmp_path):
+    """Round 6: two-sided calls lay ONE grid over both clouds (grid2.h); with PCU_HIP_BRICK=1 the fused Chamfer sum of float32 clouds takes the
+    LDS-staged lane pass (csrc/search_brick.h) instead of k_search1_flat. Same check as above -- the C ABI's fp64 means against the fp64 sum of
+    the k = 1 rows, 1e-10 -- in a child process with the switch set, on a uniform pair at the headline's density (every block staged), sizes that
+    leave a partial last block, clouds of different size, and inputs whose blocks fall back to the global scan (plane, clusters: short uneven rows);
+    the rows come from THIS process (k_nearest_neighbors: per-cloud grids, k_search1_flat)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng([SEED, 777])
+    cases = [("uniform", "uniform", 1_000_000, 1_000_000), ("uniform", "uniform", 300_001, 170_003), ("uniform", "uniform", 5_000, 9_000),
+             ("plane", "uniform", 90_000, 120_000), ("clusters", "mixed", 150_000, 100_000), ("sphere", "sphere", 200_000, 200_000)]
+    arrs = {}
+    for i, (dq, dr, n, m) in enumerate(cases):
+        arrs[f"x{i}"], arrs[f"y{i}"] = make(rng, n, dq, np.float32), make(rng, m, dr, np.float32)
+    np.savez(tmp_path / "in.npz", **arrs)
+    code = (
+        "import sys, ctypes, numpy as np; sys.path.insert(0, %r); import point_cloud_utils_amd as pcu\n"
+        "from point_cloud_utils_amd import _Dev, _fn, Stats\n"
+        "g = np.load(%r); out = {}\n"
+        "for i in range(%d):\n"
+        "    x, y = g['x%%d' %% i], g['y%%d' %% i]\n"
+        "    dv = _Dev(x, y); means = (ctypes.c_double * 2)(); st = Stats()\n"
+        "    for rep in range(3):\n"
+        "        rc = _fn('chamfer', dv.suffix)(dv.ctx, dv.pa, len(x), dv.pb, len(y), 2.0, 10, ctypes.addressof(means), None, None, dv.flags, dv.stream, ctypes.addressof(st))\n"
+        "        assert rc == 0\n"
+        "        out['m%%d_%%d' %% (i, rep)] = np.array([means[0], means[1]])\n"
+        "np.savez(%r, **out)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), len(cases), str(tmp_path / "out.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCU_HIP_BRICK="1"), timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(tmp_path / "out.npz")
+    for i, (dq, dr, n, m) in enumerate(cases):
+        x, y = arrs[f"x{i}"], arrs[f"y{i}"]
+        dxy, _ = pcu.k_nearest_neighbors(x, y, 1)
+        dyx, _ = pcu.k_nearest_neighbors(y, x, 1)
+        want = np.array([float(np.asarray(dxy).astype(np.float64).sum()) / n, float(np.asarray(dyx).astype(np.float64).sum()) / m])
+        for rep in range(3):
+            assert np.all(np.abs(got[f"m{i}_{rep}"] - want) <= 1e-10 * want + 1e-300), (cases[i], rep, got[f"m{i}_{rep}"], want)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("n,m", [(63, 63), (64, 64), (65, 63), (63, 5000), (5000, 63), (64, 100000), (100, 257), (1000, 1023), (1025, 700),
                                  (2047, 2047), (2048, 2048), (2049, 2047), (2047, 40000), (40000, 2047), (5000, 2049), (16383, 16384), (16384, 32767),
