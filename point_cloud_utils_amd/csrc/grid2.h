@@ -62,6 +62,15 @@ struct CellMap {
 
 __device__ __forceinline__ unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
+// The geometry of a grid as the context keeps it from one call to the next (round 6): the layout of call i is computed from call i's sample by
+// the sort launch's extra block -- off the critical path -- and USED by call i + 1, whose scatter blocks then start keying as soon as their
+// points arrive instead of first reading a sample and laying the grid out (8 of a block's 25 us). Any layout gives the same search results; one
+// that no longer fits the data (range moved by more than 5 % of the extent, cell edge by more than 4 %) is refused by the same extra block
+// (GridParams::has_large bit 8: the searches give up, the host restarts the call with a fresh layout) BEFORE the balance heuristics can mistake
+// a stale grid for uneven data.
+template <typename T> struct GridGeo { T org[3], h, inv_h, slack[3], rlo[3], rhi[3]; int G[3], ncells; };
+constexpr int kGeoStale = 8;        // GridParams::has_large bit (search.h: index_not_ready)
+
 template <typename T>
 struct Build2Side {
     const T* pts; int n; GridParams<T>* gp; int shift;
@@ -81,6 +90,8 @@ struct Build2Side {
     // read in the same order by the blocks of both sides (identical arithmetic on identical inputs: identical grids), for n_layout = the larger
     // cloud's size. spts1 == nullptr: the cloud's own grid from its own 1024 samples, as before.
     const T* spts0; int sn0; const T* spts1; int sn1; int n_layout;
+    const GridGeo<T>* geo_in;       // nullable: lay the grid out as the context's previous call did (see GridGeo)
+    GridGeo<T>* geo_out;            // nullable: where the sort launch's extra block leaves THIS call's layout for the next one
 };
 
 // A column of per-thread values (NT threads) folded by one wave: lane l takes the values of threads l, l + 64, ...; the result is valid in lane 63.
@@ -95,42 +106,18 @@ __device__ __forceinline__ T fold_column(const T* col, int kind, int lane) {
     return kind == 0 ? wave_min63(r) : (kind == 1 ? wave_max63(r) : wave_sum63(r));
 }
 
-template <typename T> struct StagedPts { static constexpr int n = sizeof(T) == 4 ? 8 : 4; };       // points per thread: 32-byte f64 records halve the block
+// The stratified sample of a build (one point per thread of a 1024-thread block) and the grid layout it gives. Shared by the scatter blocks
+// (which lay the grid out themselves when the context has no layout to hand down) and the sort launch's extra block (which computes the layout
+// the NEXT call will use). Identical arithmetic on identical inputs: identical grids, whoever computes them.
+template <typename T> struct SampleOf { T v[3]; T pv[3]; bool on; };        // (raw loads: nothing of them is looked at before the caller has issued its own loads)
 template <typename T>
-static size_t onepass3_lds_bytes() { return (size_t)kBkThreads * StagedPts<T>::n * sizeof(Pt4<T>) + (size_t)kStagedMaxBuckets * 12; }
-
-template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side<T> a0, const Build2Side<T> a1, int nb0) {
-    constexpr int PTS = StagedPts<T>::n, BLOCK_PTS = kBkThreads * PTS;
-    extern __shared__ __attribute__((aligned(32))) unsigned char s_dyn[];
-    Pt4<T>* const s_stage = reinterpret_cast<Pt4<T>*>(s_dyn);
-    T* const s_col = reinterpret_cast<T*>(s_dyn);                    // [13][kBkThreads] columns of per-thread statistics: the stage is not in use yet
-    unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_dyn + (size_t)BLOCK_PTS * sizeof(Pt4<T>));
-    unsigned* const s_lbase = s_cnt + kStagedMaxBuckets;
-    unsigned* const s_gbase = s_lbase + kStagedMaxBuckets;
-    __shared__ GridParams<T> s_gp;
-    __shared__ T s_fin[13];
-    __shared__ unsigned s_nf;                    // non-finite flags met by the block (bbox_body's bits)
-    if (threadIdx.x == 0) s_nf = 0u;
-    static_assert(13 * kBkThreads * sizeof(T) <= (size_t)BLOCK_PTS * sizeof(Pt4<T>), "the statistics columns fit the stage");
-    const bool second = (int)blockIdx.x >= nb0;
-    const Build2Side<T>& a = second ? a1 : a0;
-    const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
-    const int n = a.n, shift = a.shift;
-    const unsigned cap = a.cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = bid * BLOCK_PTS;
-    long long* const prof = a.prof;
-    long long t_prev = prof ? wall_clock64() : 0;
-#define P3_PROF(slot) do { if (prof && tid == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
-    struct __attribute__((packed, aligned(4))) P3 { T v[3]; };      // a point = ONE 12 / 24-byte load (three scalar loads cost the L1 path three requests)
+__device__ __forceinline__ SampleOf<T> sample_request(const Build2Side<T>& a, const int n, const int tid) {
+    struct __attribute__((packed, aligned(4))) P3 { T v[3]; };
     const P3* const pts3 = reinterpret_cast<const P3*>(a.pts);
-    // ---- grid layout from the sample (every block the same). The sample is requested BEFORE the block's own points: loads return in order, so
-    // the layout waits for the sample only and runs while the points are still in flight.
     const bool shared = a.spts1 != nullptr;       // (both clouds hold >= kPrepSamples points then: the host's rule)
     const bool all = !shared && n < kPrepSamples; // a cloud smaller than the sample: every point
     const int S = all ? n : kPrepSamples;
-    static_assert(kPrepSamples == kBkThreads, "one sample per thread");
+    static_assert(kPrepSamples == kBkThreads && kPrepSamples == kSortThreads, "one sample per thread");
     P3 sv, pv;
     if (!shared) {
         const int j = min(tid, S - 1);            // sample j: one point of the slice [j n / S, (j + 1) n / S), position hashed
@@ -149,23 +136,29 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
         const size_t i = (size_t)b0 + (size_t)(((unsigned long long)hash32((unsigned)tid) * (unsigned long long)(unsigned)(b1 - b0)) >> 32);
         sv = src[i]; pv = reinterpret_cast<const P3*>(a.spts0)[0];
     }
-    T px[PTS], py[PTS], pz[PTS];
+    SampleOf<T> r;
 #pragma unroll
-    for (int j = 0; j < PTS; ++j) {
-        const P3 p = pts3[min(base + j * kBkThreads + tid, n - 1)];
-        px[j] = p.v[0]; py[j] = p.v[1]; pz[j] = p.v[2];
-    }
+    for (int j = 0; j < 3; ++j) { r.v[j] = sv.v[j]; r.pv[j] = pv.v[j]; }
+    r.on = tid < S;
+    return r;
+}
+// (every thread of the 1024-thread block; s_col: 13 x 1024 scalars of scratch; two barriers inside, one at the end. gp_out: geometry fields +
+// provisional gmin / gmax = the sample's box; rng6: the range the grid was laid over, valid in thread 0)
+template <typename T>
+__device__ __forceinline__ void layout_from_sample(const Build2Side<T>& a, const int n, const SampleOf<T>& smp, T* const s_col, T* const s_fin, GridParams<T>* const gp_out, T (&rng6)[6]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool shared = a.spts1 != nullptr;
     {
         T piv[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) piv[j] = ((pv.v[j] < (T)0 ? -pv.v[j] : pv.v[j]) <= Limits<T>::max_v) ? pv.v[j] : (T)0;
+        for (int j = 0; j < 3; ++j) piv[j] = ((smp.pv[j] < (T)0 ? -smp.pv[j] : smp.pv[j]) <= Limits<T>::max_v) ? smp.pv[j] : (T)0;
         T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
         T hi[3] = {-Limits<T>::max_v, -Limits<T>::max_v, -Limits<T>::max_v};
         T s1[3] = {(T)0, (T)0, (T)0}, s2[3] = {(T)0, (T)0, (T)0}, cnt = (T)0;
-        if (tid < S) {
+        if (smp.on) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const T x = sv.v[c];
+                const T x = smp.v[c];
                 const bool fin = (x < (T)0 ? -x : x) <= Limits<T>::max_v;
                 lo[c] = fin ? x : lo[c]; hi[c] = fin ? x : hi[c];
                 const T dv = fin ? x - piv[c] : (T)0;
@@ -187,7 +180,7 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
             for (int j = 0; j < 3; ++j) {
                 T l = s_fin[j], h = s_fin[3 + j];
                 if (!(l <= h)) { l = 0; h = 0; }          // no finite value sampled in this column
-                s_gp.gmin[j] = l; s_gp.gmax[j] = h;       // (provisional: the exact box arrives with k_bucket_sort2's extra blocks)
+                gp_out->gmin[j] = l; gp_out->gmax[j] = h;       // (provisional: the exact box arrives with k_bucket_sort2's extra blocks)
                 rlo[j] = l; rhi[j] = h;
                 if (m0 > 0) {
                     const double m1 = (double)s_fin[7 + j] * inv0, var = (double)s_fin[10 + j] * inv0 - m1 * m1, sd = var > 0 ? (double)sqrtf((float)var) : 0.0, mu = (double)piv[j] + m1;
@@ -197,15 +190,73 @@ __global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Side
                         if (q < rhi[j] && q > rlo[j]) rhi[j] = q;
                     }
                 }
+                rng6[j] = rlo[j]; rng6[3 + j] = rhi[j];
             }
-            grid_layout<T>(&s_gp, rlo, rhi, shared ? a.n_layout : n, a.occupancy, a.max_cells, a.h_want);
-            if (bid == 0) {             // the side's first block publishes the geometry for the kernels that follow
-                GridParams<T>& o = *a.gp;
-                for (int j = 0; j < 3; ++j) { o.gmin[j] = s_gp.gmin[j]; o.gmax[j] = s_gp.gmax[j]; o.slack[j] = s_gp.slack[j]; o.G[j] = s_gp.G[j]; o.org[j] = s_gp.org[j]; }
-                o.h = s_gp.h; o.inv_h = s_gp.inv_h; o.ncells = s_gp.ncells; o.closed = 0; o.nonfinite = 0; o.sumsq = 0ull;
-            }
+            grid_layout<T>(gp_out, rlo, rhi, shared ? a.n_layout : n, a.occupancy, a.max_cells, a.h_want);
         }
         __syncthreads();
+    }
+}
+
+template <typename T> struct StagedPts { static constexpr int n = sizeof(T) == 4 ? 8 : 4; };       // points per thread: 32-byte f64 records halve the block
+template <typename T>
+static size_t onepass3_lds_bytes() { return (size_t)kBkThreads * StagedPts<T>::n * sizeof(Pt4<T>) + (size_t)kStagedMaxBuckets * 12; }
+
+// (the side's arguments are read through an index into the kernel-argument segment: selecting between two by-value structs by reference makes the
+// compiler copy the chosen one to scratch -- 472 bytes per lane and every field a scratch load, which doubled the layout stage when the struct grew)
+template <typename T> struct Build2Args { Build2Side<T> a[2]; };
+template <typename T>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Args<T> p, int nb0) {
+    constexpr int PTS = StagedPts<T>::n, BLOCK_PTS = kBkThreads * PTS;
+    extern __shared__ __attribute__((aligned(32))) unsigned char s_dyn[];
+    Pt4<T>* const s_stage = reinterpret_cast<Pt4<T>*>(s_dyn);
+    T* const s_col = reinterpret_cast<T*>(s_dyn);                    // [13][kBkThreads] columns of per-thread statistics: the stage is not in use yet
+    unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_dyn + (size_t)BLOCK_PTS * sizeof(Pt4<T>));
+    unsigned* const s_lbase = s_cnt + kStagedMaxBuckets;
+    unsigned* const s_gbase = s_lbase + kStagedMaxBuckets;
+    __shared__ GridParams<T> s_gp;
+    __shared__ T s_fin[13];
+    __shared__ unsigned s_nf;                    // non-finite flags met by the block (bbox_body's bits)
+    if (threadIdx.x == 0) s_nf = 0u;
+    static_assert(13 * kBkThreads * sizeof(T) <= (size_t)BLOCK_PTS * sizeof(Pt4<T>), "the statistics columns fit the stage");
+    const bool second = (int)blockIdx.x >= nb0;
+    const Build2Side<T>& a = p.a[second ? 1 : 0];
+    const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
+    const int n = a.n, shift = a.shift;
+    const unsigned cap = a.cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = bid * BLOCK_PTS;
+    long long* const prof = a.prof;
+    long long t_prev = prof ? wall_clock64() : 0;
+#define P3_PROF(slot) do { if (prof && tid == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
+    struct __attribute__((packed, aligned(4))) P3 { T v[3]; };      // a point = ONE 12 / 24-byte load (three scalar loads cost the L1 path three requests)
+    const P3* const pts3 = reinterpret_cast<const P3*>(a.pts);
+    // ---- grid layout: the context's previous one (GridGeo), or from the sample (every block the same). The sample is requested BEFORE the
+    // block's own points: loads return in order, so the layout waits for the sample only and runs while the points are still in flight.
+    const bool cached = a.geo_in != nullptr;
+    SampleOf<T> smp;
+    if (!cached) smp = sample_request<T>(a, n, tid);
+    T px[PTS], py[PTS], pz[PTS];
+#pragma unroll
+    for (int j = 0; j < PTS; ++j) {
+        const P3 p = pts3[min(base + j * kBkThreads + tid, n - 1)];
+        px[j] = p.v[0]; py[j] = p.v[1]; pz[j] = p.v[2];
+    }
+    if (cached) {
+        if (tid == 0) {                     // (a wave-uniform address: scalar loads, which do not queue behind the vector loads just issued)
+            const GridGeo<T> c = *a.geo_in;
+            for (int j = 0; j < 3; ++j) { s_gp.gmin[j] = c.rlo[j]; s_gp.gmax[j] = c.rhi[j]; s_gp.org[j] = c.org[j]; s_gp.slack[j] = c.slack[j]; s_gp.G[j] = c.G[j]; }
+            s_gp.h = c.h; s_gp.inv_h = c.inv_h; s_gp.ncells = c.ncells; s_gp.closed = 0;
+        }
+        __syncthreads();
+    } else {
+        T rng6[6];
+        layout_from_sample<T>(a, n, smp, s_col, s_fin, &s_gp, rng6);
+    }
+    if (tid == 0 && bid == 0) {             // the side's first block publishes the geometry for the kernels that follow
+        GridParams<T>& o = *a.gp;
+        for (int j = 0; j < 3; ++j) { o.gmin[j] = s_gp.gmin[j]; o.gmax[j] = s_gp.gmax[j]; o.slack[j] = s_gp.slack[j]; o.G[j] = s_gp.G[j]; o.org[j] = s_gp.org[j]; }
+        o.h = s_gp.h; o.inv_h = s_gp.inv_h; o.ncells = s_gp.ncells; o.closed = 0; o.nonfinite = 0; o.sumsq = 0ull;
     }
     const CellMap<T> cm(s_gp);
     const int NB = (uniform(s_gp.ncells) + (1 << shift) - 1) >> shift;           // (<= kStagedMaxBuckets: the host chose this kernel)
@@ -305,6 +356,38 @@ __device__ __forceinline__ void fold_xpartials(const Build2Side<T>& a) {
     __shared__ T s_lo[kSortThreads / 64][3], s_hi[kSortThreads / 64][3];
     __shared__ unsigned s_nf[kSortThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- the layout THIS call's sample gives, for the context's next call (GridGeo); and, if this call was laid out by its predecessor's, is
+    // that layout still close to it?
+    __shared__ int s_stale;
+    if (tid == 0) s_stale = 0;
+    if (a.geo_out) {
+        extern __shared__ __attribute__((aligned(32))) unsigned char s_dyn[];          // (the bucket blocks' stage: this block has no bucket)
+        T* const s_col = reinterpret_cast<T*>(s_dyn);
+        __shared__ T s_fin[13];
+        __shared__ GridParams<T> s_fresh;
+        T rng6[6];
+        const SampleOf<T> smp = sample_request<T>(a, a.n, tid);
+        layout_from_sample<T>(a, a.n, smp, s_col, s_fin, &s_fresh, rng6);
+        if (tid == 0) {
+            GridGeo<T> f;
+            for (int j = 0; j < 3; ++j) { f.org[j] = s_fresh.org[j]; f.slack[j] = s_fresh.slack[j]; f.G[j] = s_fresh.G[j]; f.rlo[j] = rng6[j]; f.rhi[j] = rng6[3 + j]; }
+            f.h = s_fresh.h; f.inv_h = s_fresh.inv_h; f.ncells = s_fresh.ncells;
+            if (a.geo_in) {
+                const GridGeo<T> u = *a.geo_in;
+                bool stale = false;
+                for (int j = 0; j < 3; ++j) {
+                    const T eu = u.rhi[j] - u.rlo[j], ef = f.rhi[j] - f.rlo[j], ext = eu > ef ? eu : ef, tol = (T)0.05 * ext;
+                    const T dl = f.rlo[j] - u.rlo[j], dh = f.rhi[j] - u.rhi[j];
+                    if (!((dl < (T)0 ? -dl : dl) <= tol) || !((dh < (T)0 ? -dh : dh) <= tol)) stale = true;
+                }
+                const T hr = f.h / u.h;
+                if (!(hr > (T)0.96 && hr < (T)1.04)) stale = true;
+                s_stale = stale ? 1 : 0;
+            }
+            *a.geo_out = f;
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < a.n_zero_next; i += kSortThreads) a.zero_next[i] = 0ull;
     for (int i = tid; i < a.n_zero2; i += kSortThreads) a.zero2[i] = 0u;
     T lo[3] = {Limits<T>::max_v, Limits<T>::max_v, Limits<T>::max_v};
@@ -337,7 +420,7 @@ __device__ __forceinline__ void fold_xpartials(const Build2Side<T>& a) {
         if (!(p <= q)) { p = 0; q = 0; }          // no finite value in this column
         gp->gmin[j] = p; gp->gmax[j] = q;
     }
-    gp->has_large = *a.ovf ? 2 : 0;
+    gp->has_large = (*a.ovf ? 2 : 0) | (s_stale ? kGeoStale : 0);
     if (a.n_large) *a.n_large = 0u;
     put_sentinels(a.sorted, a.n);
 }
@@ -550,15 +633,16 @@ __device__ __forceinline__ void sort2_bucket(const int b, const Build2Side<T>& a
     else sort2_body<T, false>(b, a, cnt_cap, s, pf, nvalid, s_cnt, s_stage, s_w, s_q, t_prev);
 }
 
-// (the side's arguments are read through an index into the kernel-argument segment: selecting between two by-value structs by reference
-// makes the compiler copy the chosen one to scratch -- with the 64-VGPR bound below that tipped the whole kernel into spilling)
-template <typename T> struct Build2Args { Build2Side<T> a[2]; };
+// (the side's arguments through an index into the kernel-argument segment, see k_bucket_onepass3)
 template <typename T>
-__global__ __launch_bounds__(kSortThreads) void k_bucket_sort2(const Build2Args<T> p, int nb0, int nb1, int cnt_cap) {
+__global__ __launch_bounds__(kSortThreads) void k_bucket_sort2(const Build2Args<T> p, int nb0, int nb1, int cnt_cap, int nfold) {
+    // The launch's FIRST blocks, one per cloud, are the extra blocks (fold_xpartials): since round 6 they also compute the layout the context's next
+    // call will use (a cold sample read + the serial layout: longer than a bucket), and as the launch's last blocks they ended it 5 us late.
     const int bid = (int)blockIdx.x;
-    if (bid >= nb0 + nb1) { fold_xpartials<T>(p.a[bid == nb0 + nb1 ? 0 : 1]); return; }       // the launch's last blocks: one per cloud
-    const int side = bid >= nb0 ? 1 : 0;
-    sort2_bucket<T>(side ? bid - nb0 : bid, p.a[side], cnt_cap);
+    if (bid < nfold) { fold_xpartials<T>(p.a[bid]); return; }
+    const int b = bid - nfold;
+    const int side = b >= nb0 ? 1 : 0;
+    sort2_bucket<T>(side ? b - nb0 : b, p.a[side], cnt_cap);
 }
 
 // The Pt4 records of a LEAN index from its two streams (for the kernels that read whole records: k > 1 lane passes, row-based epilogues,

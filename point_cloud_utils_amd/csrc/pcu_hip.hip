@@ -237,6 +237,8 @@ struct pcu_hip_ctx {
                                                                  // fill_parity -- left zeroed by its predecessor -- and zeroes the other one for its successor
     char* aux = nullptr; size_t aux_cap = 0;  // grow-only block for operators that run a search as a sub-step (normals): survives the
                                               // sub-call's use of the arena
+    // grid2.h: GridGeo -- the layout of this context's last two-sided fused build, per cloud, on the device; what it was computed for, on the host
+    struct GeoCache { char* dev = nullptr; bool valid[2] = {false, false}; int n[2] = {0, 0}; double occ = 0, h_want = 0; int max_cells = 0, n_layout = 0, tsize = 0; bool shared = false; } geo;
     bool brick_off = false;                   // sticky: a staged k = 1 pass of this context (search_brick.h) fell back to global scans in more than a quarter of its
                                               // blocks (surfaces, clusters: short uneven rows): its fused calls take k_search1_flat on per-cloud grids again
     unsigned cancel_epoch = 0;                // g_cancel_epoch at this context's last call (ctx_begin: reset of the cross-call device state after an abandoned call)
@@ -336,6 +338,7 @@ static int ctx_begin(pcu_hip_ctx* c, size_t want_bytes) {
         if (c->fill2) HIP_TRY(hipMemset(c->fill2, 0, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
         c->fill_parity = 0;
         c->kd_spec.active = c->kd_spec.pending = false;
+        c->geo.valid[0] = c->geo.valid[1] = false;
         c->cancel_epoch = ep;
     }
     want_bytes += c->extra_hint;                // what earlier calls had to hipMalloc on top of their estimate (refitted / coarse grids)
@@ -484,7 +487,7 @@ static BucketSide<T> bucket_side(const GridIndex<T>& g, const T* pts) {
 }
 template <typename T>
 static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex<T>* b, const T* pb, double occb, hipStream_t s,
-                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, pcu_hip_ctx* ctx = nullptr) {
+                            bool defer_large = false, void* zero2 = nullptr, int n_zero2 = 0, pcu_hip_ctx* ctx = nullptr, bool keep_layout = false) {
     a.src = pa; a.occ_built = occa;
     if (b) { b->src = pb; b->occ_built = occb; }
     // one launch set serves both clouds only if they are built the same way
@@ -512,7 +515,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             return Build2Side<T>{p, g.n, g.gp, g.shift, occ, g.max_cells, g.h_want, fw + (size_t)k * kStagedMaxBuckets, fw + 2 * kStagedMaxBuckets + k,
                                  g.tmp, kLargeBucket, g.xpartial, (g.n + bpts - 1) / bpts, g.cell_start, g.sorted, g.pos_of, g.lean ? 0 : 1, g.n_large,
                                  k == 0 ? fw_next : nullptr, k == 0 ? kFillWords : 0, k == 0 ? (unsigned*)zero2 : nullptr, k == 0 ? n_zero2 : 0, nullptr,
-                                 p, g.n, nullptr, 0, g.n};
+                                 p, g.n, nullptr, 0, g.n, nullptr, nullptr};
         };
         Build2Side<T> s0 = side(a, pa, occa, 0), s1 = b ? side(*b, pb, occb, 1) : s0;
         // one grid for both clouds (GridIndex::shared_grid): same plan (index_alloc's n_plan), same occupancy, both at least a sample large
@@ -522,6 +525,21 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         if (shared) {
             s0.spts0 = s1.spts0 = pa; s0.sn0 = s1.sn0 = a.n; s0.spts1 = s1.spts1 = pb; s0.sn1 = s1.sn1 = b->n;
             s0.n_layout = s1.n_layout = std::max(a.n, b->n);
+        }
+        // The layout handed down from the context's previous call (grid2.h: GridGeo): two-sided fused calls only (their *_end knows how to restart a
+        // call whose layout was refused as stale). The key: everything grid_layout and the sample depend on besides the points themselves.
+        static const bool geo_off = getenv("PCU_HIP_NO_GEO_CACHE") != nullptr;
+        if (keep_layout && b && !geo_off && ctx->geo.dev && a.n >= kPrepSamples && b->n >= kPrepSamples) {
+            pcu_hip_ctx::GeoCache& gc = ctx->geo;
+            const bool hit = gc.valid[0] && gc.valid[1] && gc.n[0] == a.n && gc.n[1] == b->n && gc.occ == occa && occa == occb && gc.h_want == a.h_want && a.h_want == b->h_want &&
+                             gc.max_cells == a.max_cells && a.max_cells == b->max_cells && gc.shared == shared && gc.n_layout == s0.n_layout && gc.tsize == (int)sizeof(T);
+            static_assert(sizeof(GridGeo<T>) <= 256, "two layouts fit the context's block");
+            GridGeo<T>* const g0 = reinterpret_cast<GridGeo<T>*>(gc.dev), *const g1 = reinterpret_cast<GridGeo<T>*>(gc.dev + 256);
+            s0.geo_out = g0; s1.geo_out = g1;
+            if (hit) { s0.geo_in = g0; s1.geo_in = g1; }
+            if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[layout] handed down: %d (n %d %d, shared %d)\n", (int)hit, a.n, b->n, (int)shared);
+            gc.valid[0] = gc.valid[1] = occa == occb && a.h_want == b->h_want && a.max_cells == b->max_cells;
+            gc.n[0] = a.n; gc.n[1] = b->n; gc.occ = occa; gc.h_want = a.h_want; gc.max_cells = a.max_cells; gc.shared = shared; gc.n_layout = s0.n_layout; gc.tsize = (int)sizeof(T);
         }
         const int c0 = s0.n_xpart, c1 = b ? s1.n_xpart : 0;
         static const bool do_prof2 = getenv("PCU_HIP_PROF_BUILD2") != nullptr;
@@ -534,7 +552,8 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
         }
-        hipLaunchKernelGGL(k_bucket_onepass3<T>, dim3(c0 + c1), dim3(kBkThreads), onepass3_lds_bytes<T>(), s, s0, s1, c0);
+        Build2Args<T> sa; sa.a[0] = s0; sa.a[1] = s1;
+        hipLaunchKernelGGL(k_bucket_onepass3<T>, dim3(c0 + c1), dim3(kBkThreads), onepass3_lds_bytes<T>(), s, sa, c0);
         if (do_prof2) {
             long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
             const double nb = h[15] > 0 ? (double)h[15] * 100.0 : 100.0;
@@ -544,8 +563,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         const int t0 = a.nb_max, t1 = b ? b->nb_max : 0;
         const int cnt_cap = 1 << std::max(a.shift, b ? b->shift : 0);
         if (do_prof2) { HIP_TRY(hipMemsetAsync(prof2, 0, 16 * sizeof(long long), s)); }
-        Build2Args<T> sa; sa.a[0] = s0; sa.a[1] = s1;
-        hipLaunchKernelGGL(k_bucket_sort2<T>, dim3(t0 + t1 + (b ? 2 : 1)), dim3(kSortThreads), bucket_sort_lds_bytes<T>(cnt_cap), s, sa, t0, t1, cnt_cap);
+        hipLaunchKernelGGL(k_bucket_sort2<T>, dim3(t0 + t1 + (b ? 2 : 1)), dim3(kSortThreads), bucket_sort_lds_bytes<T>(cnt_cap), s, sa, t0, t1, cnt_cap, b ? 2 : 1);
         ctx->fill_parity ^= 1;        // only now: both launches are enqueued, so the other set WILL be zeroed for the next build (an error return above leaves the parity alone)
         if (do_prof2) {
             long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
@@ -1895,6 +1913,8 @@ static int pair_search_enqueue(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, p
 // deferred next to a heavy cell)? Then run it now, fold again, and wait for that result block.
 template <typename T>
 static int fused_wave_if_needed(pcu_hip_ctx* c, hipStream_t s, PairState<T>& P, pcu_hip_stats* st, ResultBlock& host) {
+    // The layout handed down from the previous call no longer fits these clouds (grid2.h: kGeoStale; every pass gave up): once more, laid out afresh.
+    if ((host.counters[0][C_LARGE] | (P.two ? host.counters[1][C_LARGE] : 0)) & kGeoStale) { c->geo.valid[0] = c->geo.valid[1] = false; return PCU_RETRY; }
     if (P.xy.brick) {           // the staged pass's report: blocks that scanned from global memory (search_brick.h)
         const long long fb = (long long)host.counters[0][C_SPARE] + host.counters[1][C_SPARE], nb = (long long)P.xy.n_flat + P.yx.n_flat;
         if (4 * fb > nb) c->brick_off = true;
@@ -1985,7 +2005,7 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
     g_hprof.mark(1);
     // (the first build's first kernel also zeroes the call block: both directions' counters, the epilogue's ticket, the exact sums)
     // (defer_large: the placement of over-full buckets is launched only if a search reports them, see search_finish)
-    if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c)) return -1;
+    if (index_build_pair<T>(ix, P.dx, occ_x, &iy, P.dy, occ_y, s, /*defer_large=*/!c->eager_large, P.cb, (int)(sizeof(CallBlock) / 4), c, /*keep_layout=*/P.fuse != FUSE_NONE)) return -1;
     P.xy.qidx.lean = P.yx.ridx.lean = ix.lean; P.xy.ridx.lean = P.yx.qidx.lean = iy.lean;      // (the build says what it wrote)
     P.xy.qidx.shared_grid = P.yx.ridx.shared_grid = ix.shared_grid; P.xy.ridx.shared_grid = P.yx.qidx.shared_grid = iy.shared_grid;
     {   // shared grid + fused sum + float: the staged lane pass (search_brick.h); its per-block partials follow its block size
@@ -2217,7 +2237,7 @@ static int hausdorff_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, i
     if (validate_sizes(nx, ny, "source", "targets")) return PCU_HIP_ERR_INVALID;
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE, squared = flags & PCU_HIP_SQUARED;
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
-    if (st) memset(st, 0, sizeof *st);
+    if (st) { const int builds = pp.restarts ? st->n_grid_builds : 0; memset(st, 0, sizeof *st); st->n_grid_builds = builds; }      // (a restarted call reports the builds of its abandoned attempts too)
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
@@ -2334,7 +2354,7 @@ static int chamfer_begin(pcu_hip_ctx* c, const T* x, int64_t nx, const T* y, int
     if (isnan(p_norm)) return fail(PCU_HIP_ERR_INVALID, "p_norm is NaN");
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
     hipStream_t s = (stream || (flags & PCU_HIP_STREAM_GIVEN)) ? (hipStream_t)stream : c->own_stream;
-    if (st) memset(st, 0, sizeof *st);
+    if (st) { const int builds = pp.restarts ? st->n_grid_builds : 0; memset(st, 0, sizeof *st); st->n_grid_builds = builds; }      // (a restarted call reports the builds of its abandoned attempts too)
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ_x = call_occupancy(c, 1, 0), occ_y = call_occupancy(c, 1, 1);
     if (ctx_begin(c, pair_bytes<T>(nx, ny, occ_x, occ_y, on_dev))) return PCU_HIP_ERR_RUNTIME;
@@ -2745,6 +2765,7 @@ int pcu_hip_ctx_create(int device, pcu_hip_ctx** out_ctx) {
     memset(c->h_pinned, 0, 128 * sizeof(int));
     HIP_TRY(hipMalloc((void**)&c->tickets, 64 * sizeof(unsigned)));
     HIP_TRY(hipMemset(c->tickets, 0, 64 * sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&c->geo.dev, 512));
     HIP_TRY(hipMalloc((void**)&c->fill2, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->fill2, 0, 2 * (size_t)kFillWords * sizeof(unsigned long long)));
     *out_ctx = c;
@@ -2761,6 +2782,7 @@ void pcu_hip_ctx_destroy(pcu_hip_ctx* c) {
     if (c->aux) (void)hipFree(c->aux);
     if (c->tickets) (void)hipFree(c->tickets);
     if (c->fill2) (void)hipFree(c->fill2);
+    if (c->geo.dev) (void)hipFree(c->geo.dev);
     if (c->arena) (void)hipFree(c->arena);
     for (hipEvent_t e : {c->kd_spec.ev_fork, c->kd_spec.ev_init, c->kd_spec.ev_done}) if (e) (void)hipEventDestroy(e);
     kd_graph_drop(c);

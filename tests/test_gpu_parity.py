@@ -739,3 +739,29 @@ def test_max_points_per_leaf_decides_tie_order(pcu, oracle_kind, dtype, leaf):
             oracle.hausdorff_distance(a, b, return_index=True, max_points_per_leaf=leaf, kind=oracle_kind)
         assert pcu.one_sided_hausdorff_distance(a, b, max_points_per_leaf=leaf) == \
             oracle.one_sided_hausdorff_distance(a, b, max_points_per_leaf=leaf, kind=oracle_kind)
+
+
+def test_layout_handed_down_between_calls(pcu, oracle_kind):
+    """Round 6: a context hands the grid layout of one fused two-sided call to the next (csrc/grid2.h: GridGeo) -- the scatter blocks of call i + 1
+    key their points on call i's layout while the sort launch's extra block computes call i + 1's own from its sample and refuses the inherited
+    one if it no longer fits (range moved by > 5 % of the extent, cell edge by > 4 %): the searches give up, the call restarts on a fresh layout.
+    A sequence of same-sized pairs whose geometry jumps -- scaled, shifted, shrunk, reshaped -- must give the reference's values whatever the
+    previous call was; the statistics show which calls were restarted (4 index builds instead of 2)."""
+    n, m = 180_000, 150_000
+    rng = np.random.default_rng(606)
+    base_x, base_y = rng.random((n, 3)).astype(np.float32), rng.random((m, 3)).astype(np.float32)
+    steps = [("same", 1.0, 0.0), ("same again", 1.0, 0.0), ("jitter 1 %", 1.01, 0.002), ("scaled x3", 3.0, 0.0), ("shifted +10", 3.0, 10.0),
+             ("shrunk x0.1", 0.1, 10.0), ("back", 1.0, 0.0)]
+    builds = []
+    for tag, sc, off in steps:
+        x = (base_x * np.float32(sc) + np.float32(off)).astype(np.float32); y = (base_y * np.float32(sc) + np.float32(off)).astype(np.float32)
+        ch = pcu.chamfer_distance(x, y)
+        builds.append(pcu.last_stats()["n_grid_builds"])
+        ch0 = oracle.chamfer_distance(x, y, kind=oracle_kind)
+        assert abs(float(ch) - float(ch0)) <= 1e-4 * float(ch0), (tag, ch, ch0)
+        assert pcu.hausdorff_distance(x, y, return_index=True) == oracle.hausdorff_distance(x, y, return_index=True, kind=oracle_kind), tag
+    g = rng.normal(0.5, 0.05, (n, 3)).astype(np.float32); h = rng.normal(0.5, 0.05, (m, 3)).astype(np.float32)        # another shape altogether
+    assert abs(float(pcu.chamfer_distance(g, h)) - float(oracle.chamfer_distance(g, h, kind=oracle_kind))) <= 1e-4 * float(pcu.chamfer_distance(g, h))
+    if os.environ.get("PCU_HIP_NO_GEO_CACHE") is None and os.environ.get("PCU_HIP_NO_FUSE") is None and os.environ.get("PCU_HIP_BUILD_V1") is None:
+        assert builds[1] == 2 and builds[2] == 2, builds          # steady state and a 1 % drift: the inherited layout stands
+        assert builds[3] == 4 and builds[4] == 4 and builds[5] == 4, builds      # jumps: refused, restarted
