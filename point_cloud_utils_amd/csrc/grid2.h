@@ -199,26 +199,33 @@ __device__ __forceinline__ void layout_from_sample(const Build2Side<T>& a, const
 }
 
 template <typename T> struct StagedPts { static constexpr int n = sizeof(T) == 4 ? 8 : 4; };       // points per thread: 32-byte f64 records halve the block
+// Dynamic LDS of a scatter block of kBkThreads x pts points with tables for nbcap buckets: the stage + three words per bucket; never less than
+// the 13 statistics columns of the layout stage (which lie over stage and tables: they are done before the tables are zeroed).
 template <typename T>
-static size_t onepass3_lds_bytes() { return (size_t)kBkThreads * StagedPts<T>::n * sizeof(Pt4<T>) + (size_t)kStagedMaxBuckets * 12; }
+static size_t onepass3_lds_bytes(int pts = StagedPts<T>::n, int nbcap = kStagedMaxBuckets) {
+    return std::max((size_t)kBkThreads * pts * sizeof(Pt4<T>) + (size_t)nbcap * 12, (size_t)13 * kBkThreads * sizeof(T));
+}
 
 // (the side's arguments are read through an index into the kernel-argument segment: selecting between two by-value structs by reference makes the
 // compiler copy the chosen one to scratch -- 472 bytes per lane and every field a scratch load, which doubled the layout stage when the struct grew)
 template <typename T> struct Build2Args { Build2Side<T> a[2]; };
-template <typename T>
-__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Args<T> p, int nb0) {
-    constexpr int PTS = StagedPts<T>::n, BLOCK_PTS = kBkThreads * PTS;
+// PTS points per thread (round 6: chosen by the host so that a launch has about a block per CU or more -- 8192-point blocks left three quarters of
+// the GPU empty on config 4's 262 144-point clouds -- and, below 8, so that two blocks fit a CU's LDS and overlap their phases); nbcap: bucket
+// slots of the three tables (>= the grid's bucket count, a multiple of 64).
+template <typename T, int PTS>
+__global__ __launch_bounds__(kBkThreads) void k_bucket_onepass3(const Build2Args<T> p, int nb0, int nbcap) {
+    constexpr int BLOCK_PTS = kBkThreads * PTS;
     extern __shared__ __attribute__((aligned(32))) unsigned char s_dyn[];
     Pt4<T>* const s_stage = reinterpret_cast<Pt4<T>*>(s_dyn);
     T* const s_col = reinterpret_cast<T*>(s_dyn);                    // [13][kBkThreads] columns of per-thread statistics: the stage is not in use yet
     unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_dyn + (size_t)BLOCK_PTS * sizeof(Pt4<T>));
-    unsigned* const s_lbase = s_cnt + kStagedMaxBuckets;
-    unsigned* const s_gbase = s_lbase + kStagedMaxBuckets;
+    unsigned* const s_lbase = s_cnt + nbcap;
+    unsigned* const s_gbase = s_lbase + nbcap;
     __shared__ GridParams<T> s_gp;
     __shared__ T s_fin[13];
     __shared__ unsigned s_nf;                    // non-finite flags met by the block (bbox_body's bits)
     if (threadIdx.x == 0) s_nf = 0u;
-    static_assert(13 * kBkThreads * sizeof(T) <= (size_t)BLOCK_PTS * sizeof(Pt4<T>), "the statistics columns fit the stage");
+    static_assert(6 * kBkThreads * sizeof(T) <= (size_t)BLOCK_PTS * sizeof(Pt4<T>), "the six columns of the block's exact partial fit the stage (the 13 of the layout may lie over the tables: onepass3_lds_bytes)");
     const bool second = (int)blockIdx.x >= nb0;
     const Build2Side<T>& a = p.a[second ? 1 : 0];
     const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;

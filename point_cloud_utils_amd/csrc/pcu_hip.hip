@@ -430,7 +430,7 @@ static size_t index_bytes(int64_t n, double occ) {
     if (bucket_plan(n, occ, &sh, &nb))
         b += align_up(std::max((size_t)n, (size_t)nb * kLargeBucket) * sizeof(Pt4<T>), 256) + 2 * align_up((size_t)(nb + 1) * 4, 256) +
              align_up((size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * nb * 4, 256) +
-             align_up((size_t)((n + 4095) / 4096) * kXPartStride * sizeof(T), 256);
+             align_up((size_t)((n + 2047) / 2048) * kXPartStride * sizeof(T), 256);
     return b;
 }
 template <typename T>
@@ -457,7 +457,7 @@ static int index_alloc(Arena& a, GridIndex<T>& g, int64_t n, double occ, bool wa
         if (aalloc(a, &g.tmp, one_pass ? std::max((size_t)n, (size_t)g.nb_max * kLargeBucket) : (size_t)n)) return -1;
         if (aalloc(a, &g.bucket_start, (size_t)g.nb_max + 1) || aalloc(a, &g.large_list, (size_t)g.nb_max + 1)) return -1;
         if (aalloc(a, &g.block_base, (size_t)((n + kBkBlockPts - 1) / kBkBlockPts) * g.nb_max)) return -1;
-        if (one_pass && aalloc(a, &g.xpartial, (size_t)((n + 4095) / 4096) * kXPartStride)) return -1;
+        if (one_pass && aalloc(a, &g.xpartial, (size_t)((n + 2047) / 2048) * kXPartStride)) return -1;        // (one partial per scatter block: 2048 points at least, grid2.h)
         g.pos_of = want_pos ? g.cell_of : nullptr;      // cell_of is not used by this build
     } else {
         g.pos_of = g.rank;                              // k_scatter turns rank into the slot, in place
@@ -510,7 +510,19 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         kBkThreads * StagedPts<T>::n >= run_floor) {
         unsigned long long* const fw = ctx->fill2 + (size_t)ctx->fill_parity * kFillWords;
         unsigned long long* const fw_next = ctx->fill2 + (size_t)(ctx->fill_parity ^ 1) * kFillWords;
-        const int bpts = kBkThreads * StagedPts<T>::n;
+        // points per thread of the scatter blocks: the most (longest runs per (block, bucket), fewest reservations); PCU_HIP_BUILD_PTS fixes it (A/B)
+        static const int pts_env = getenv("PCU_HIP_BUILD_PTS") ? atoi(getenv("PCU_HIP_BUILD_PTS")) : 0;
+        int pts = StagedPts<T>::n;
+        {
+            const long long ntot = (long long)a.n + (b ? b->n : 0);
+            static const int n_cu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+            // (measured, profiles/r06_build_ab.txt: halving the blocks to get a block per CU -- or two per CU at 2 x 1M -- LOSES: every stage of a
+            // block takes as long with half the points, reservations and padding double; only launches of a handful of blocks are cut up)
+            while (pts > 2 && (ntot + (long long)kBkThreads * pts - 1) / ((long long)kBkThreads * pts) < n_cu / 16 && kBkThreads * (pts / 2) >= run_floor) pts /= 2;
+            if (pts_env == 2 || pts_env == 4 || pts_env == 8) pts = std::min(pts_env, (int)StagedPts<T>::n);
+        }
+        const int bpts = kBkThreads * pts;
+        const int nbcap = (std::max(a.nb_max, b ? b->nb_max : 0) + 63) / 64 * 64;
         auto side = [&](const GridIndex<T>& g, const T* p, double occ, int k) {
             return Build2Side<T>{p, g.n, g.gp, g.shift, occ, g.max_cells, g.h_want, fw + (size_t)k * kStagedMaxBuckets, fw + 2 * kStagedMaxBuckets + k,
                                  g.tmp, kLargeBucket, g.xpartial, (g.n + bpts - 1) / bpts, g.cell_start, g.sorted, g.pos_of, g.lean ? 0 : 1, g.n_large,
@@ -548,12 +560,17 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         s0.prof = s1.prof = do_prof2 ? prof2 : nullptr;
         static std::atomic<unsigned long long> attr_set2[2];
         if (attr_unset_here(attr_set2[sizeof(T) == 4 ? 0 : 1])) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>()));
+            if (StagedPts<T>::n >= 8) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>(8)));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>(4)));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_onepass3<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)onepass3_lds_bytes<T>(2)));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_sort2<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)bucket_sort_lds_bytes<T>(kBkMaxCellsPerBucket)));
         }
         Build2Args<T> sa; sa.a[0] = s0; sa.a[1] = s1;
-        hipLaunchKernelGGL(k_bucket_onepass3<T>, dim3(c0 + c1), dim3(kBkThreads), onepass3_lds_bytes<T>(), s, sa, c0);
+        const size_t lds1 = onepass3_lds_bytes<T>(pts, nbcap);
+        if (pts == 8) hipLaunchKernelGGL((k_bucket_onepass3<T, 8>), dim3(c0 + c1), dim3(kBkThreads), lds1, s, sa, c0, nbcap);
+        else if (pts == 4) hipLaunchKernelGGL((k_bucket_onepass3<T, 4>), dim3(c0 + c1), dim3(kBkThreads), lds1, s, sa, c0, nbcap);
+        else hipLaunchKernelGGL((k_bucket_onepass3<T, 2>), dim3(c0 + c1), dim3(kBkThreads), lds1, s, sa, c0, nbcap);
         if (do_prof2) {
             long long h[16]; HIP_TRY(hipMemcpyAsync(h, prof2, sizeof h, hipMemcpyDeviceToHost, s)); HIP_WAIT(s);
             const double nb = h[15] > 0 ? (double)h[15] * 100.0 : 100.0;

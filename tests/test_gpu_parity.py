@@ -746,7 +746,22 @@ def test_layout_handed_down_between_calls(pcu, oracle_kind):
     key their points on call i's layout while the sort launch's extra block computes call i + 1's own from its sample and refuses the inherited
     one if it no longer fits (range moved by > 5 % of the extent, cell edge by > 4 %): the searches give up, the call restarts on a fresh layout.
     A sequence of same-sized pairs whose geometry jumps -- scaled, shifted, shrunk, reshaped -- must give the reference's values whatever the
-    previous call was; the statistics show which calls were restarted (4 index builds instead of 2)."""
+    previous call was; the statistics show which calls were restarted (4 index builds instead of 2). Run on a thread of its own, i.e. in a fresh
+    context (_lib.ctx is per thread): what earlier tests left sticky in this thread's context -- a finer occupancy for surfaces, the two-pass build
+    after an overflow -- decides whether the handed-down layout is used at all."""
+    import threading
+    err = []
+    def body():
+        try:
+            _layout_sequence(pcu, oracle_kind)
+        except BaseException as e:          # noqa: BLE001 -- re-raised on the test's thread
+            err.append(e)
+    th = threading.Thread(target=body); th.start(); th.join()
+    if err:
+        raise err[0]
+
+
+def _layout_sequence(pcu, oracle_kind):
     n, m = 180_000, 150_000
     rng = np.random.default_rng(606)
     base_x, base_y = rng.random((n, 3)).astype(np.float32), rng.random((m, 3)).astype(np.float32)
