@@ -754,6 +754,12 @@ static double call_occupancy(const pcu_hip_ctx* c, int k, int role) { return c->
 #endif
 constexpr int kWaveBlocks = PCU_WAVE_BLOCKS;    // fixed grid of the wave-cooperative passes: 2048 waves striding a device-side list
 
+// ONE grid over both clouds of a two-sided call (grid2.h: Build2Side::spts1; what search_brick.h's staged pass needs): clouds of comparable size
+// indexed at the same occupancy. PCU_HIP_NO_SHARED_GRID=1: every cloud its own grid, as before round 6.
+static bool shared_grid_wanted(const pcu_hip_ctx* c, int64_t nx, int64_t ny, double occ_x, double occ_y) {
+    static const bool off = getenv("PCU_HIP_NO_SHARED_GRID") != nullptr;
+    return !off && !c->brick_off && occ_x == occ_y && std::min(nx, ny) >= kPrepSamples && std::max(nx, ny) <= 2 * std::min(nx, ny);
+}
 // whole-call index builds use the one-pass bucket scatter until a cloud of this context overflows a slot (PCU_HIP_TWO_PASS=1: never)
 static bool use_one_pass(const pcu_hip_ctx* c) { static const bool off = getenv("PCU_HIP_TWO_PASS") != nullptr; return !off && !c->two_pass; }
 // The wave-per-query launch of a call finishes its stragglers itself (search.h: k_search_wave, box round -> ball round); PCU_HIP_NO_ESCALATE=1
@@ -1754,7 +1760,11 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
     c->time_phases = flags & PCU_HIP_TIME_PHASES; c->time_kernels = flags & PCU_HIP_TIME_KERNELS;
     const double occ = pidx ? pidx->occ : call_occupancy(c, k, 1);
     const double occ_q = 2.0;
-    size_t need = (pidx ? 0 : index_bytes<T>(nr, occ)) + index_bytes<T>(nq, occ_q) + scratch_bytes<T>(nq) + 8192 +
+    // (one grid over query cloud and dataset when they are of comparable size and occupancy -- k = 1: the lanes of a wave then look at neighbouring
+    // cells of one dataset row, profiles/r06_flat_aligned_ab.txt; both indexes are planned for the larger cloud)
+    const bool share = !pidx && shared_grid_wanted(c, nq, nr, occ_q, occ);
+    const int64_t n_plan = share ? std::max(nq, nr) : 0;
+    size_t need = (pidx ? 0 : index_bytes<T>(std::max(nr, n_plan), occ)) + index_bytes<T>(std::max(nq, n_plan), occ_q) + scratch_bytes<T>(nq) + 8192 +
                   align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);     // cell-ordered results
     if (!on_dev) need += align_up((size_t)nq * 3 * sizeof(T), 256) + (pidx ? 0 : align_up((size_t)nr * 3 * sizeof(T), 256)) +
                          align_up((size_t)nq * k * sizeof(T), 256) + align_up((size_t)nq * k * 8, 256);
@@ -1779,8 +1789,9 @@ static int knn_attempt(pcu_hip_ctx* c, const T* query, int64_t nq, const T* data
         const bool row_out = k >= row_out_min_k;
         job.row_out = row_out;
         if (pidx) job.ridx = index_grid<T>(pidx);
-        else if ((rc = index_alloc(ar, job.ridx, nr, occ, false, true, use_one_pass(c)))) break;
-        if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/!row_out, true, use_one_pass(c)))) break;
+        else if ((rc = index_alloc(ar, job.ridx, nr, occ, false, true, use_one_pass(c), n_plan))) break;
+        if ((rc = index_alloc(ar, job.qidx, nq, occ_q, /*want_pos=*/!row_out, true, use_one_pass(c), n_plan))) break;
+        job.ridx.shared_grid = job.qidx.shared_grid = share;
         job.qidx.src = dq; job.qidx.occ_built = occ_q;
         if (!pidx) { job.ridx.src = dr; job.ridx.occ_built = occ; }
         ResultBlock* rb = nullptr;
@@ -1889,12 +1900,6 @@ struct PairState {
     bool wave_pending = false;                          // the fused attempt's wave-per-query pass has not been launched (pair_search_enqueue)
     int* tie_hit = nullptr;
 };
-// ONE grid over both clouds of a two-sided call (grid2.h: Build2Side::spts1; what search_brick.h's staged pass needs): clouds of comparable size
-// indexed at the same occupancy. PCU_HIP_NO_SHARED_GRID=1: every cloud its own grid, as before round 6.
-static bool shared_grid_wanted(const pcu_hip_ctx* c, int64_t nx, int64_t ny, double occ_x, double occ_y) {
-    static const bool off = getenv("PCU_HIP_NO_SHARED_GRID") != nullptr;
-    return !off && !c->brick_off && occ_x == occ_y && std::min(nx, ny) >= kPrepSamples && std::max(nx, ny) <= 2 * std::min(nx, ny);
-}
 template <typename T>
 static size_t pair_bytes(int64_t nx, int64_t ny, double occ_x, double occ_y, bool on_dev) {
     // (index_bytes of the LARGER cloud for both: a shared grid is planned for it, index_alloc's n_plan)

@@ -331,7 +331,9 @@ __device__ __forceinline__ double kill_if(double d, bool dead) {
 }
 // Certification, output and list appends of one lane (shared by the gather and the LDS-tile main passes).
 // `valid` is false for padding lanes of a partial wave (they only take part in the wave-wide list appends).
-template <typename T, int K>
+// POS: the ids in bi[] are record positions in the dataset's cell order (k_search_runs reads the coordinates-only stream, which has no row ids);
+// the rows are looked up here, once, for the kreq best.
+template <typename T, int K, bool POS = false>
 __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridParams<T>& g, const Pt4<T>& q, int qpos,
                                             int x0, int x1, int y0, int y1, int z0, int z1, T (&bd)[K], int (&bi)[K], bool tie, bool valid,
                                             bool defer = false) {
@@ -353,7 +355,7 @@ __device__ __forceinline__ void finish_lane(const SearchArgs<T>& a, const GridPa
         for (int i = 0; i < K; ++i) {
             if (i < kreq) {
                 const bool found = bi[i] != 0x7fffffff;
-                a.out_i[o + i] = found ? (long long)bi[i] : -1ll;
+                a.out_i[o + i] = found ? (long long)(POS ? a.ref_idx[bi[i]] : bi[i]) : -1ll;
                 a.out_d[o + i] = found ? (a.squared ? bd[i] : sqrt(bd[i])) : (T)-1;
             }
         }
@@ -1046,8 +1048,11 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
 // Candidates are still the 16 / 32-byte Pt4 records (a candidate that is accepted needs its row id at once), slots past a run's end read the
 // +inf sentinel record (a record offered twice would sit twice in the list), accepted candidates are parked and inserted in bursts exactly
 // as in k_search: same offers, same tie flags, same certification (finish_lane). Closed sub-box levels keep k_search.
+#ifndef PCU_RUNS_MINW
+#define PCU_RUNS_MINW 1
+#endif
 template <typename T, int K>
-__global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && K == 16) ? PCU_RUNS_MINW : 1) void k_search_runs(const SearchArgs<T> a) {
     static_assert(K > 1, "k = 1 has k_search1_flat");
     const int per = (int)(gridDim.x >> 3);
     const int vb = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // XCD-aware block order, see k_search
@@ -1085,22 +1090,36 @@ __global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
             if (i < cnt) offer<T, K>(s_bd[i][tid], s_bi[i][tid], bd, bi, tie);
         cnt = 0;
     };
-    const char* const base = reinterpret_cast<const char*>(a.ref);
     const unsigned sentinel = a.n_ref;
-    // four records from record p on, slots at or past record e replaced by the sentinel
-    auto load_group = [&](unsigned p, unsigned e, Pt4<T> (&c)[kGroup]) {
+#ifndef PCU_RUNS_XYZ
+#define PCU_RUNS_XYZ 0
+#endif
+    // Round 6 (PCU_RUNS_XYZ=1; measured equal to slightly slower on config 3, profiles/r06_c3_ab.txt -- off): candidates from the coordinates-only stream (12 / 24 bytes per record: a group of four = THREE 16-byte gathers instead of
+    // four, and 12 instead of 16 registers per group in flight), as the k = 1 kernel's do; an accepted candidate is parked with its POSITION in
+    // the stream, and the rows of the kreq best are looked up once, at the end (finish_lane<POS>). Slots at or past the run's end e are real
+    // records of the next cells (or the +inf sentinels): their distance is replaced by +inf -- a record offered twice would sit twice in the list.
+    constexpr bool XYZ = PCU_RUNS_XYZ != 0;
+    typedef GroupEval<T, true> GE;
+    struct Grp { typename GE::Raw raw; Pt4<T> c[XYZ ? 1 : kGroup]; unsigned p, e; };
+    const char* const base = reinterpret_cast<const char*>(a.ref);
+    const char* const xbase = reinterpret_cast<const char*>(a.ref_xyz);
+    auto load_group = [&](unsigned p, unsigned e, Grp& gr) {
+        gr.p = p; gr.e = e;
+        if (XYZ) { gr.raw = GE::load(xbase, rec_bytes<GE::kRec>(p)); return; }
 #pragma unroll
-        for (int u = 0; u < kGroup; ++u) {
+        for (int u = 0; u < (XYZ ? 1 : kGroup); ++u) {
             const unsigned idx = (p + u < e) ? p + u : sentinel;
-            c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
+            gr.c[u] = *reinterpret_cast<const Pt4<T>*>(base + (size_t)(idx * (unsigned)sizeof(Pt4<T>)));
         }
     };
-    auto eval_group = [&](const Pt4<T> (&c)[kGroup]) {
+    auto eval_group = [&](const Grp& gr) {
+        T dd[kGroup];
+        if (XYZ) GE::dists(gr.raw, q, dd);
 #pragma unroll
         for (int u = 0; u < kGroup; ++u) {
-            const T d = dist2(q, c[u]);
+            const T d = XYZ ? kill_if(dd[u], gr.p + (unsigned)u >= gr.e) : dist2(q, gr.c[XYZ ? 0 : u]);
             tie = tie || (d == bd[K - 1]);            // as offer() would flag it (the k-th best may be stale: conservative)
-            if (d < bd[K - 1]) { s_bd[cnt][tid] = d; s_bi[cnt][tid] = (int)c[u].idx; ++cnt; }
+            if (d < bd[K - 1]) { s_bd[cnt][tid] = d; s_bi[cnt][tid] = XYZ ? (int)(gr.p + (unsigned)u) : (int)gr.c[XYZ ? 0 : u].idx; ++cnt; }
         }
         if (__any(cnt > kBuf - kGroup)) flush();
     };
@@ -1135,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
     bool defer = cnt0 > cand_cap;
     if (!defer && cnt0 > 0u) {
         unsigned p = c_s;
-        Pt4<T> ca[kGroup], cb[kGroup];
+        Grp ca, cb;
         load_group(p, c_e, ca);
         for (;;) {
             p += kGroup;
@@ -1202,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
     };
     next_run();
     if (live) {
-        Pt4<T> ga[kGroup], gb[kGroup];
+        Grp ga, gb;
         load_group(p, end, ga);
         for (;;) {
             p += kGroup;
@@ -1218,8 +1237,8 @@ __global__ __launch_bounds__(kBlock) void k_search_runs(const SearchArgs<T> a) {
         }
     }
     if (__any(cnt > 0)) flush();
-    finish_lane<T, K>(a, g, q, qpos, max(ccx - 1, 0), min(ccx + 1, Gx - 1), max(ccy - 1, 0), min(ccy + 1, Gy - 1), max(ccz - 1, 0), min(ccz + 1, Gz - 1),
-                      bd, bi, tie, true, defer);
+    finish_lane<T, K, XYZ>(a, g, q, qpos, max(ccx - 1, 0), min(ccx + 1, Gx - 1), max(ccy - 1, 0), min(ccy + 1, Gy - 1), max(ccz - 1, 0), min(ccz + 1, Gz - 1),
+                           bd, bi, tie, true, defer);
 }
 
 // Both directions of a two-sided call (x in y, y in x) in ONE launch: blocks [0, nb0) serve a0, the rest a1.
