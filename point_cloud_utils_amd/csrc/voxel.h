@@ -6,8 +6,8 @@
 // std::unordered_map (output in hash-table order, an artefact of libstdc++) and the second with libigl's sortrows. Here:
 //   1. one kernel computes the key triple of every point with the reference's arithmetic (voxel index = int(floor((p - min) /
 //      size)) in the point type; rounded coordinate = round(p / eps));
-//   2. three STABLE radix-sort passes (rocPRIM device radix sort -- the HBM-bound integer primitive of the platform) order the
-//      point ids lexicographically by (k0, k1, k2); equal keys stay in input order;
+//   2. the triple is packed into one key of as many bits as the components' ranges need and the point ids are ordered by the repo's own STABLE
+//      radix passes (radix.h; rounds 3-5: three rocPRIM radix sorts of full 32-bit keys): lexicographic by (k0, k1, k2), equal keys in input order;
 //   3. run heads are flagged and scanned into run ids;
 //   4. one thread per run adds its points IN INPUT ORDER in the point / attribute type -- exactly the sequence of additions
 //      AccumulatedPoint::AddPoint performs (:119-128) -- so the voxel means are bit-identical to the reference's; duplicates
@@ -16,10 +16,9 @@
 // is libigl's unique_rows order). The reference's voxel output order is its hash table's and is not reproducible.
 #pragma once
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 #include "pcu_types.h"
 #include "grid.h"
+#include "radix.h"
 
 namespace pcu {
 

@@ -72,22 +72,67 @@ static int morton_knn_impl(pcu_hip_ctx* c, const C* codes, int64_t n, const C* q
 }
 
 // ---------------------------------------------------------------------------------------------------- sort by a key triple
-// perm_out: point ids ordered lexicographically by (k0, k1, k2), equal triples in input order. Three stable LSD passes
-// (rocPRIM radix sort of (key, id) pairs), least significant component first; ids must hold 0..n-1 on entry.
+// inclusive scan of n unsigned values (radix.h: tiles, one block over the tile sums, add)
+static int own_inclusive_scan(Arena& ar, hipStream_t s, const unsigned* in, unsigned* out, size_t n) {
+    const int nt = (int)((n + kScTile - 1) / kScTile);
+    unsigned* sums = nullptr;
+    if (aalloc(ar, &sums, (size_t)nt + 1)) return -1;
+    hipLaunchKernelGGL(k_sc_tiles, dim3(nt), dim3(1024), 0, s, in, out, (int)n, sums);
+    if (nt > 1) {
+        hipLaunchKernelGGL(k_sc_sums, dim3(1), dim3(1024), 0, s, sums, nt);
+        hipLaunchKernelGGL(k_sc_add, dim3(nt), dim3(1024), 0, s, out, (int)n, sums);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// Stable LSD radix sort of (key, id) pairs by the low `bits` bits of the keys (radix.h); ids == nullptr on entry: the identity. On return
+// *keys / *ids point at the buffers that hold the result (the pairs ping-pong between the given buffers).
+static int own_radix_sort(Arena& ar, hipStream_t s, unsigned long long** keys, unsigned long long** keys_alt, unsigned** ids, unsigned** ids_alt, bool ids_identity, int n, int bits) {
+    const int nwt = (n + kRsWaveTile - 1) / kRsWaveTile;
+    unsigned *hist = nullptr, *total = nullptr;
+    if (aalloc(ar, &hist, (size_t)256 * nwt) || aalloc(ar, &total, 256)) return -1;
+    const int nblk = (nwt + kRsThreads / 64 - 1) / (kRsThreads / 64);
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(kRsThreads), 0, s, *keys, n, shift, nwt, hist);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(1024), 0, s, hist, nwt, total);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(kRsThreads), 0, s, *keys, ids_identity ? (const unsigned*)nullptr : *ids, n, shift, nwt, hist, total, *keys_alt, *ids_alt);
+        std::swap(*keys, *keys_alt); std::swap(*ids, *ids_alt);
+        ids_identity = false;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static int bits_of(unsigned long long v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+// perm_out: point ids ordered lexicographically by (k0, k1, k2), equal triples in input order. The components are packed, each less its
+// minimum, into one key of as many bits as their ranges need and sorted by the repo's own stable radix passes (radix.h); triples wider than
+// 64 bits in total are sorted component by component, least significant first. One host read-back (the components' ranges).
 template <typename K>
-static int sort_by_triple(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, unsigned* ids, int n, unsigned** perm_out) {
-    K *ka = nullptr, *kb = nullptr; unsigned* alt = nullptr;
-    if (aalloc(ar, &ka, (size_t)n) || aalloc(ar, &kb, (size_t)n) || aalloc(ar, &alt, (size_t)n)) return -1;
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, ids, alt, (size_t)n, 0u, (unsigned)(8 * sizeof(K)), s));
-    char* tmp = nullptr;
-    if (aalloc(ar, &tmp, tmp_bytes + 256)) return -1;
-    const K* comps[3] = {k2, k1, k0};
+static int sort_by_triple(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, unsigned* ids, int n, unsigned** perm_out, const unsigned long long** sorted_keys = nullptr) {
+    if (sorted_keys) *sorted_keys = nullptr;
+    KeyRange* rng = nullptr;
+    unsigned long long *ka = nullptr, *kb = nullptr; unsigned* alt = nullptr;
+    if (aalloc(ar, &rng, 1) || aalloc(ar, &ka, (size_t)n) || aalloc(ar, &kb, (size_t)n) || aalloc(ar, &alt, (size_t)n)) return -1;
+    HIP_TRY(hipMemsetAsync(rng->lo, 0xff, sizeof rng->lo, s));
+    HIP_TRY(hipMemsetAsync(rng->hi, 0, sizeof rng->hi, s));
+    const int nb = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((k_key_range<K>), dim3(std::min(nb, 256)), dim3(kBlock), 0, s, k0, k1, k2, n, rng);
+    KeyRange h;
+    HIP_TRY(hipMemcpyAsync(&h, rng, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_WAIT(s);
+    const int w[3] = {bits_of(h.hi[0] - h.lo[0]), bits_of(h.hi[1] - h.lo[1]), bits_of(h.hi[2] - h.lo[2])};
     unsigned *cur = ids, *nxt = alt;
-    for (int pass = 0; pass < 3; ++pass) {
-        hipLaunchKernelGGL((k_gather_keys<K>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, comps[pass], cur, n, ka);
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, ka, kb, cur, nxt, (size_t)n, 0u, (unsigned)(8 * sizeof(K)), s));
-        std::swap(cur, nxt);
+    if (w[0] + w[1] + w[2] <= 64) {
+        hipLaunchKernelGGL((k_key_pack<K>), dim3(nb), dim3(kBlock), 0, s, k0, k1, k2, n, rng, w[1], w[2], ka);
+        if (own_radix_sort(ar, s, &ka, &kb, &cur, &nxt, /*ids_identity=*/true, n, w[0] + w[1] + w[2])) return -1;      // (0 bits: every triple equal, ids stay the identity)
+        if (sorted_keys) *sorted_keys = ka;
+    } else {
+        const K* comps[3] = {k2, k1, k0};
+        bool identity = true;
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL((k_key_gather<K>), dim3(nb), dim3(kBlock), 0, s, comps[pass], identity ? (const unsigned*)nullptr : cur, n, rng, 2 - pass, ka);
+            if (own_radix_sort(ar, s, &ka, &kb, &cur, &nxt, identity, n, w[2 - pass])) return -1;
+            if (w[2 - pass] > 0) identity = false;
+        }
     }
     HIP_TRY(hipGetLastError());
     *perm_out = cur;
@@ -95,15 +140,12 @@ static int sort_by_triple(Arena& ar, hipStream_t s, const K* k0, const K* k1, co
 }
 // head flags + inclusive scan of a sorted order -> (flag, scan); the number of runs is scan[n-1]
 template <typename K>
-static int runs_of(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, const unsigned* perm, int n, unsigned** flag_out, unsigned** scan_out) {
+static int runs_of(Arena& ar, hipStream_t s, const K* k0, const K* k1, const K* k2, const unsigned* perm, int n, unsigned** flag_out, unsigned** scan_out, const unsigned long long* sorted_keys = nullptr) {
     unsigned *flag = nullptr, *scan = nullptr;
     if (aalloc(ar, &flag, (size_t)n) || aalloc(ar, &scan, (size_t)n + 1)) return -1;
-    hipLaunchKernelGGL((k_run_heads<K>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, k0, k1, k2, perm, n, flag);
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, flag, scan, (size_t)n, rocprim::plus<unsigned>(), s));
-    char* tmp = nullptr;
-    if (aalloc(ar, &tmp, tmp_bytes + 256)) return -1;
-    HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, flag, scan, (size_t)n, rocprim::plus<unsigned>(), s));
+    if (sorted_keys) hipLaunchKernelGGL(k_run_heads_sorted, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sorted_keys, n, flag);
+    else hipLaunchKernelGGL((k_run_heads<K>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, k0, k1, k2, perm, n, flag);
+    if (own_inclusive_scan(ar, s, flag, scan, (size_t)n)) return -1;
     *flag_out = flag; *scan_out = scan;
     return 0;
 }
@@ -129,7 +171,7 @@ static int voxel_downsample_impl(pcu_hip_ctx* c, const T* pts, int64_t n, const 
     const bool on_dev = flags & PCU_HIP_PTRS_ON_DEVICE;
     hipStream_t s = pick_stream(c, flags, stream);
     const size_t N = (size_t)n;
-    size_t need = 16 * align_up(N * 4, 256) + (1 << 20) + (on_dev ? 0 : 2 * (align_up(N * 3 * sizeof(T), 256) + align_up(N * (size_t)cols * sizeof(A), 256)));
+    size_t need = 20 * align_up(N * 4, 256) + (1 << 20) + (on_dev ? 0 : 2 * (align_up(N * 3 * sizeof(T), 256) + align_up(N * (size_t)cols * sizeof(A), 256)));
     if (ctx_begin(c, need + 65536)) return PCU_HIP_ERR_RUNTIME;
     Arena ar{c};
     int rc = 0;
@@ -144,19 +186,16 @@ static int voxel_downsample_impl(pcu_hip_ctx* c, const T* pts, int64_t n, const 
         const int nb = (int)((n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL((k_voxel_keys<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, (int)n, vs[0], vs[1], vs[2], mn[0], mn[1], mn[2], k0, k1, k2, ids);
         unsigned *perm = nullptr, *flag = nullptr, *scan = nullptr;
-        if ((rc = sort_by_triple<int>(ar, s, k0, k1, k2, ids, (int)n, &perm))) break;
-        if ((rc = runs_of<int>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan))) break;
+        const unsigned long long* skeys = nullptr;
+        if ((rc = sort_by_triple<int>(ar, s, k0, k1, k2, ids, (int)n, &perm, &skeys))) break;
+        if ((rc = runs_of<int>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan, skeys))) break;
         unsigned *start = nullptr, *keep = nullptr, *keep_scan = nullptr;
         if ((rc = aalloc(ar, &start, N + 1)) || (rc = aalloc(ar, &keep, N)) || (rc = aalloc(ar, &keep_scan, N))) break;
         hipLaunchKernelGGL(k_run_starts, dim3(nb), dim3(kBlock), 0, s, flag, scan, (int)n, start);
         const unsigned* n_runs_dev = scan + (n - 1);
         HIP_TRY(hipMemsetAsync(keep, 0, N * 4, s));
         hipLaunchKernelGGL(k_run_keep, dim3(nb), dim3(kBlock), 0, s, start, n_runs_dev, min_pts, keep);
-        size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, keep, keep_scan, N, rocprim::plus<unsigned>(), s));
-        char* tmp = nullptr;
-        if ((rc = aalloc(ar, &tmp, tmp_bytes + 256))) break;
-        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, keep, keep_scan, N, rocprim::plus<unsigned>(), s));
+        if ((rc = own_inclusive_scan(ar, s, keep, keep_scan, N))) break;
         hipLaunchKernelGGL((k_voxel_means<T, A>), dim3(nb), dim3(kBlock), 0, s, d_pts, d_attr, cols, perm, start, n_runs_dev, keep, keep_scan, d_out_v, d_out_a);
         HIP_TRY(hipGetLastError());
         unsigned n_out = 0;
@@ -197,8 +236,9 @@ static int dedup_impl(pcu_hip_ctx* c, const T* pts, int64_t n, double epsilon, T
         const int nb = (int)((n + kBlock - 1) / kBlock);
         hipLaunchKernelGGL((k_round_keys<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, (int)n, (T)epsilon, k0, k1, k2, ids);
         unsigned *perm = nullptr, *flag = nullptr, *scan = nullptr;
-        if ((rc = sort_by_triple<K>(ar, s, k0, k1, k2, ids, (int)n, &perm))) break;
-        if ((rc = runs_of<K>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan))) break;
+        const unsigned long long* skeys = nullptr;
+        if ((rc = sort_by_triple<K>(ar, s, k0, k1, k2, ids, (int)n, &perm, &skeys))) break;
+        if ((rc = runs_of<K>(ar, s, k0, k1, k2, perm, (int)n, &flag, &scan, skeys))) break;
         hipLaunchKernelGGL((k_dedup_write<T>), dim3(nb), dim3(kBlock), 0, s, d_pts, perm, flag, scan, (int)n, d_out, d_svi, d_svj);
         HIP_TRY(hipGetLastError());
         unsigned n_out = 0;
