@@ -1112,8 +1112,11 @@ __device__ __forceinline__ void kd_search_one(const KdSearchArgs<T>& a, const in
     Frame f; f.node = 0; f.stage = 0; f.mindistsq = distsq; f.other = 0; f.idx = 0; f.cut = 0; f.dst = 0;
     // `f` is the frame on top (kept in registers, wave-uniform); st[] holds the frames below it.
     unsigned steps = 0;
+    long long t_poll = wall_clock64();
     while (true) {
-        if ((++steps & (BIG ? 63u : 1023u)) == 0u && cancel_seen(a.cancel_word, a.cancel_gen)) return;      // the call has been abandoned: so is this traversal (BIG: a step can be a k-wide insertion)
+        // the call has been abandoned: so is this traversal. (The request word lives in host memory -- a PCIe round trip per look: at most one per
+        // 200 us of a wave's life, the clock read every 64 steps)
+        if ((++steps & 63u) == 0u) { const long long t_now = wall_clock64(); if (t_now - t_poll > 20000ll) { t_poll = t_now; if (cancel_seen(a.cancel_word, a.cancel_gen)) return; } }
         const KdNode<T>& nd = a.nodes[f.node];
         bool pop = false;
         if (f.stage == 0) {
@@ -1235,10 +1238,12 @@ __global__ __launch_bounds__(64) void k_kd_search_all(const KdSearchArgs<T> a) {
     T* rd; int* ri;
     if (a.rs_d) { rd = a.rs_d + (size_t)blockIdx.x * a.k; ri = a.rs_i + (size_t)blockIdx.x * a.k; }
     else { rd = reinterpret_cast<T*>(s_rs); ri = reinterpret_cast<int*>(s_rs + (size_t)a.k * sizeof(T)); }
+    long long t_poll = wall_clock64();
     for (int t = blockIdx.x; t < a.nq_raw; t += gridDim.x) {
         Pt4<T> q; q.x = a.qraw[3 * (size_t)t]; q.y = a.qraw[3 * (size_t)t + 1]; q.z = a.qraw[3 * (size_t)t + 2]; q.idx = t;
         kd_search_one<T, true>(a, t, (int)blockIdx.x, q, (size_t)t, rd, ri, s_dists, s_vec);
-        if (*(volatile int*)a.error_flag || cancel_seen(a.cancel_word, a.cancel_gen)) return;
+        if (*(volatile int*)a.error_flag) return;
+        { const long long t_now = wall_clock64(); if (t_now - t_poll > 20000ll) { t_poll = t_now; if (cancel_seen(a.cancel_word, a.cancel_gen)) return; } }
         __syncthreads();
     }
 }

@@ -833,7 +833,10 @@ template <typename T>
 static int launch_search_wave(int K, const SearchArgs<T>& a, hipStream_t s, const SearchArgs<T>* a1 = nullptr) {
     // lists: fixed grid striding a device-side count; whole-cloud passes (a.nq given): one wave per query up to 64k waves
     // (fused calls: the fixed grid always -- the arg-max slots are one per wave of that grid)
-    const int blocks = (a.qcount_dev || a.fuse != FUSE_NONE) ? kWaveBlocks : std::max(1, std::min((a.nq + (a1 && !a1->qcount_dev ? a1->nq : 0) + 3) / 4, 16384));
+    // (round 6: long lists per lane -- K >= 16, registers for 3 waves per SIMD at most -- take twice the grid: config 3's 4.5k stragglers and
+    // possible ties 3.45 -> 3.30 ms; at K = 2 the larger grid costs the Gaussian cloud's 33k-straggler pass 3 %, profiles/r06_c3_ab.txt)
+    const int list_blocks = (K >= 16 && a.fuse == FUSE_NONE) ? 2 * kWaveBlocks : kWaveBlocks;
+    const int blocks = (a.qcount_dev || a.fuse != FUSE_NONE) ? list_blocks : std::max(1, std::min((a.nq + (a1 && !a1->qcount_dev ? a1->nq : 0) + 3) / 4, 16384));
     dim3 grid(blocks), block(kBlock);
 #define PCU_CASE(KK) case KK: hipLaunchKernelGGL((k_search_wave<T, KK>), grid, block, 0, s, a, a1 ? *a1 : a, a1 ? 2 : 1, blocks); break;
     switch (K) {
@@ -1730,6 +1733,7 @@ static int knn_big_k(pcu_hip_ctx* c, const T* query, int64_t nq, const T* datase
         int herr = 0;
         HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
         if (!on_dev) {
+            HIP_WAIT(s);        // (the traversal first, cancellably: copies to pageable memory block the host until they are done -- hundreds of MB here)
             HIP_TRY(hipMemcpyAsync(out_d, dd, (size_t)nq * k * sizeof(T), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_i, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         }

@@ -1320,8 +1320,11 @@ __global__ __launch_bounds__(kBlock) void k_search_wave(const SearchArgs<T> a0, 
     if (njobs > 1 && a1.skew_limit > 0.f && ((float)ss1 > a1.skew_limit || (float)ss1 < a1.skew_lo)) { if (wave == 0 && lane == 0) *a1.skew_flag = (float)ss1 > a1.skew_far ? 2 : 1; total1 = 0; }
     if (hl0) { if (wave == 0 && lane == 0) a0.skew_flag[kLargeFlag] = hl0; total0 = 0; }
     if (njobs > 1 && hl1) { if (wave == 0 && lane == 0) a1.skew_flag[kLargeFlag] = hl1; total1 = 0; }
+    long long t_poll = wall_clock64();
     for (int wg = wave; wg < total0 + total1; wg += nwaves) {
-        if (wg != wave && cancel_seen(a0.cancel_word, a0.cancel_gen)) break;       // (from a wave's second work item on: short launches never look)
+        // (cancellation: one uncached host-memory load, i.e. a PCIe round trip -- at most once per 200 us of a wave's life; looking between ALL work
+        // items made a 33k-straggler launch 7 x slower: 2048 waves x 16 items queueing on the link, profiles/r06_configs.jsonl history)
+        { const long long t_now = wall_clock64(); if (t_now - t_poll > 20000ll) { t_poll = t_now; if (cancel_seen(a0.cancel_word, a0.cancel_gen)) break; } }
         const bool job1 = wg >= total0;
         const SearchArgs<T>& a = job1 ? a1 : a0;
         const int w = job1 ? wg - total0 : wg;
