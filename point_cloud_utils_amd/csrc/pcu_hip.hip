@@ -796,7 +796,10 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
 #ifndef PCU_FLAT_MINW
 #define PCU_FLAT_MINW 8
 #endif
-#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, (sizeof(T) == 4 && FUSE == FUSE_SUM) ? PCU_FLAT_MINW : 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
+#ifndef PCU_FLAT_MINW_ROWS
+#define PCU_FLAT_MINW_ROWS 4
+#endif
+#define PCU_FLAT(FUSE) hipLaunchKernelGGL((k_search1_flat<T, false, sizeof(T) == 4 ? (FUSE == FUSE_SUM ? PCU_FLAT_MINW : PCU_FLAT_MINW_ROWS) : 4, FUSE>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0)
         // (a variant that deals a wave's candidate groups evenly to its lanes -- LDS list + atomic min -- measured 75.6 vs 76.5 us: the loop is
         // not where the instructions are, profiles/r04_flat_deal_ab.txt; removed)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
