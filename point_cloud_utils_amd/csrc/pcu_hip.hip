@@ -803,6 +803,7 @@ static int launch_search_fast(int K, const SearchArgs<T>& a, int nwork, hipStrea
         // (a variant that deals a wave's candidate groups evenly to its lanes -- LDS list + atomic min -- measured 75.6 vs 76.5 us: the loop is
         // not where the instructions are, profiles/r04_flat_deal_ab.txt; removed)
         if (a.fuse == FUSE_SUM) PCU_FLAT(FUSE_SUM);
+        else if (a.fuse == FUSE_ARGMAX && a.maxval && (!a1 || a1->maxval)) hipLaunchKernelGGL((k_search1_flat<T, false, sizeof(T) == 4 ? PCU_FLAT_MINW : 4, FUSE_MAXVAL>), dim3(g0 + g1), dim3(tb), 0, s, p2, g0);
         else if (a.fuse == FUSE_ARGMAX) PCU_FLAT(FUSE_ARGMAX);
         else PCU_FLAT(FUSE_NONE);
 #undef PCU_FLAT
@@ -894,6 +895,7 @@ struct SearchJob {           // one direction: queries of `qidx` against the dat
     SearchScratch<T> sc;
     // fused epilogue (reduce.h): per-block partials of the k = 1 lane pass instead of result rows
     int fuse = FUSE_NONE; int n_flat = 0;
+    bool maxval = false;                        // fused arg-max: value-only lane pass, the winner's neighbour resolved by k_fuse_tail (reduce.h: FuseTail::maxval)
     bool brick = false;                         // the lane pass is search_brick.h's staged pass (shared grid, fused sum, float)
     double* f_sum = nullptr; T* f_max_v = nullptr; long long* f_max_k = nullptr;
     unsigned long long* f_limbs = nullptr; double* f_special = nullptr; T* f_wave_v = nullptr; long long* f_wave_k = nullptr;
@@ -920,7 +922,7 @@ static SearchArgs<T> base_args(const SearchJob<T>& j, const GridIndex<T>& ridx) 
     a.f_limbs = j.f_limbs; a.f_special = j.f_special; a.f_wave_v = j.f_wave_v; a.f_wave_k = j.f_wave_k; a.f_accum = 0;
     a.bad_r = j.bad_r; a.bad_q = j.bad_q; a.escalate = 0;
     a.cancel_word = g_cancel_mirror.load(std::memory_order_relaxed); a.cancel_gen = t_call_gen;
-    a.brick = j.brick ? 1 : 0; a.n_fallback = j.sc.counters + C_SPARE;
+    a.brick = j.brick ? 1 : 0; a.n_fallback = j.sc.counters + C_SPARE; a.maxval = j.maxval ? 1 : 0;
     return a;
 }
 
@@ -2019,6 +2021,11 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
             t.flat_sum[d] = J.f_sum; t.flat_v[d] = J.f_max_v; t.flat_k[d] = J.f_max_k; t.nflat[d] = J.n_flat;
             t.wave_v[d] = J.f_wave_v; t.wave_k[d] = J.f_wave_k; t.limbs[d] = J.f_limbs; t.special[d] = J.f_special;
         }
+        {   // Hausdorff: the value-only lane pass + the tail's resolution of the one winning query (PCU_HIP_NO_MAXVAL=1: the winner-tracking lane pass)
+            static const bool maxval_off = getenv("PCU_HIP_NO_MAXVAL") != nullptr;
+            t.maxval = (fuse_mode == FUSE_ARGMAX && !maxval_off) ? 1 : 0; t.squared = squared ? 1 : 0;
+            P.xy.maxval = P.yx.maxval = t.maxval != 0;
+        }
         t.result_block = reinterpret_cast<const int*>(P.rb); t.host_block = c->h_pinned; t.seq = ++c->seq;
         t.w_sums = (int)(offsetof(ResultBlock, sums) / 4); t.w_vals = (int)(offsetof(ResultBlock, vals) / 4);
         t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;
@@ -2043,6 +2050,11 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
         const bool brick = sizeof(T) == 4 && P.fuse == FUSE_SUM && two_sided && ix.shared_grid && iy.shared_grid && brick_env_on && !c->brick_off;
         P.xy.brick = P.yx.brick = brick;
         if (brick) for (int d = 0; d < 2; ++d) { SearchJob<T>& J = d ? P.yx : P.xy; J.n_flat = grid8(J.qidx.n, kBrickNT); P.tail.nflat[d] = J.n_flat; }
+    }
+    if (P.fuse == FUSE_ARGMAX) for (int d = 0; d < (two_sided ? 2 : 1); ++d) {       // what the tail needs to resolve a winner: the direction's dataset index and query stream
+        const SearchJob<T>& J = d ? P.yx : P.xy;
+        P.tail.r_gp[d] = J.ridx.gp; P.tail.r_cs[d] = J.ridx.cell_start; P.tail.r_xyz[d] = xyz_of(J.ridx.sorted, J.ridx.n); P.tail.r_idx[d] = idx32_of(J.ridx.sorted, J.ridx.n);
+        P.tail.q_xyz[d] = xyz_of(J.qidx.sorted, J.qidx.n);
     }
     if (st) st->n_grid_builds += 2;
     tm.mark(1);

@@ -118,7 +118,8 @@ __device__ __forceinline__ double exact_term(const unsigned long long* limbs, co
     const unsigned long long v = __hip_atomic_load(&limbs[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v ? ldexp((double)v, 32 * l - 1074) : 0.0;
 }
-enum { FUSE_NONE = 0, FUSE_SUM = 1, FUSE_ARGMAX = 2 };
+enum { FUSE_NONE = 0, FUSE_SUM = 1, FUSE_ARGMAX = 2, FUSE_MAXVAL = 3 };      // (MAXVAL: a variant of the lane kernel only -- see FuseTail::maxval; everything else says ARGMAX)
+constexpr long long kKeyUnresolved = 1ll << 30;      // FUSE_MAXVAL keys: low word = this bit | the query's position in its cloud's cell order (clouds hold < 2^27 rows)
 constexpr int kTailThreads = 1024;
 // Arguments of k_fuse_tail, the one-block launch that ends a fused call.
 template <typename T>
@@ -130,7 +131,66 @@ struct FuseTail {
     unsigned long long* limbs[2]; double* special[2];                                          // the wave pass's exact sums
     const int* result_block; int* host_block; unsigned seq;
     int w_sums, w_vals, w_ij, w_tie;             // word offsets of sums[2] / vals / ij[4] / tie[2] inside the result block
+    // Round 6, Hausdorff (FUSE_ARGMAX with maxval != 0): the lane pass ran its VALUE-ONLY program (search.h: FUSE_MAXVAL -- the fused sum's scan with
+    // adoption, about half the cost of the winner-tracking one) and its partials name the arg-max QUERY, not its neighbour: key = source row << 32 |
+    // kKeyUnresolved | query position. The one query that wins is resolved here, by this block: it scans the 5 x 5 x 5 cells around the query (the lane
+    // pass certified its value inside the 27, or inside these by its radius-2 rescue) in the distance's own arithmetic, takes the minimum, and
+    // reports the dataset row -- or, if two records share the minimum, the tie flag, which sends the call to the row-based path as before.
+    int maxval, squared;
+    const GridParams<T>* r_gp[2]; const unsigned* r_cs[2]; const T* r_xyz[2]; const int* r_idx[2]; const T* q_xyz[2];
 };
+
+// The nearest dataset record of a query among the 5 x 5 x 5 cells around it: its row, and whether a second record lies at exactly the same squared
+// distance. The block serves BOTH directions at once -- threads [0, NT/2) direction 0, the rest direction 1, 16 threads per row of the box -- because
+// the resolution is a chain of four dependent round trips (query + grid -> row bounds -> records -> row id), not work: one after the other they
+// cost 12 us, side by side 5. need[d]: direction d has a winner to resolve at position qpos[d]. Results valid in every thread.
+template <typename T, int NT>
+__device__ __forceinline__ void tail_resolve2(const FuseTail<T>& ft, const bool (&need)[2], const unsigned (&qpos)[2], long long (&j_out)[2], int (&tie_out)[2], T (&min_d2)[2]) {
+    constexpr int H = NT / 2, HW = H / 64;
+    static_assert(H / 16 >= 25, "a row of the box per 16 threads");
+    __shared__ T s_d[NT / 64]; __shared__ unsigned s_pos[NT / 64], s_cnt[NT / 64];
+    const int tid = threadIdx.x, d = tid >= H ? 1 : 0, lt = tid - d * H;
+    T best = Limits<T>::max_v; unsigned pos = 0xffffffffu, cnt = 0;
+    if (need[d]) {
+        const GridParams<T>& g = *ft.r_gp[d];
+        const T* const qp = ft.q_xyz[d] + 3 * (size_t)qpos[d];
+        const T qx = qp[0], qy = qp[1], qz = qp[2];
+        const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
+        const int cx = grid_cell(g, 0, qx), cy = grid_cell(g, 1, qy), cz = grid_cell(g, 2, qz);
+        const int bx0 = max(cx - 2, 0), bx1 = min(cx + 2, Gx - 1), by0 = max(cy - 2, 0), by1 = min(cy + 2, Gy - 1), bz0 = max(cz - 2, 0), bz1 = min(cz + 2, Gz - 1);
+        const int ny = by1 - by0 + 1, nrows = ny * (bz1 - bz0 + 1);
+        const int r = lt >> 4, sl = lt & 15;
+        if (r < nrows) {
+            const unsigned lo = (unsigned)row_run_lo(Gx, grid_row(Gy, by0 + r % ny, bz0 + r / ny), bx0, bx1);
+            const unsigned s = ft.r_cs[d][lo], e = ft.r_cs[d][lo + (unsigned)(bx1 - bx0 + 1)];
+            const T* const xyz = ft.r_xyz[d];
+            for (unsigned i = s + (unsigned)sl; i < e; i += 16u) {
+                const T dx = qx - xyz[3 * (size_t)i], dy = qy - xyz[3 * (size_t)i + 1], dz = qz - xyz[3 * (size_t)i + 2];
+                const T dd = ((dx * dx) + (dy * dy)) + (dz * dz);         // (the distance's own arithmetic: nanoflann.hpp:496-507)
+                if (dd < best) { best = dd; pos = i; cnt = 1; } else if (dd == best) { ++cnt; pos = i < pos ? i : pos; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {          // (a wave belongs to one direction: H is a multiple of 64)
+        const T d2 = __shfl_xor(best, o, 64); const unsigned p2 = (unsigned)__shfl_xor((int)pos, o, 64), c2 = (unsigned)__shfl_xor((int)cnt, o, 64);
+        if (d2 < best) { best = d2; pos = p2; cnt = c2; } else if (d2 == best) { cnt += c2; pos = p2 < pos ? p2 : pos; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_d[tid >> 6] = best; s_pos[tid >> 6] = pos; s_cnt[tid >> 6] = cnt; }
+    __syncthreads();
+#pragma unroll
+    for (int dd_ = 0; dd_ < 2; ++dd_) {
+        T bd = s_d[dd_ * HW]; unsigned bp = s_pos[dd_ * HW], bc = s_cnt[dd_ * HW];
+        for (int w = 1; w < HW; ++w) {
+            const T d2 = s_d[dd_ * HW + w]; const unsigned p2 = s_pos[dd_ * HW + w], c2 = s_cnt[dd_ * HW + w];
+            if (d2 < bd) { bd = d2; bp = p2; bc = c2; } else if (d2 == bd) { bc += c2; bp = p2 < bp ? p2 : bp; }
+        }
+        min_d2[dd_] = bd;
+        j_out[dd_] = (need[dd_] && bp != 0xffffffffu) ? (long long)ft.r_idx[dd_][bp] : 0x7fffffffll;
+        tie_out[dd_] = (bc > 1u || bp == 0xffffffffu) ? 1 : 0;
+    }
+}
 
 // ONE block folds a fused call: the lane pass's per-block partials (k_search1_flat), the wave pass's share (exact limbs or
 // per-wave arg-max partials), both directions; the results and the search counters of the call's result block go to pinned
@@ -226,21 +286,48 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     }
     const int rbw = tid < 63 ? ft.result_block[tid] : 0;
     if (tid == 0) s_mask = 0ull;
+    if (ft.mode == FUSE_SUM) {
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-        if (jb >= ft.njobs) continue;
-        if (ft.mode == FUSE_SUM) {
+        for (int jb = 0; jb < 2; ++jb) {
+            if (jb >= ft.njobs) continue;
             const double r = tail_sum<NT>(acc[jb], s_d);
             if (tid == 0) { *reinterpret_cast<double*>(&s_res[ft.w_sums + 2 * jb]) = r; s_mask |= 3ull << (ft.w_sums + 2 * jb); }
-        } else {
+        }
+    } else {
+        VK win[2] = {best[0], best[1]};
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            if (jb >= ft.njobs) continue;
             VK v = best[jb];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v = comb_max(v, shfl_vk(v, o));
             __syncthreads();
             if ((tid & 63) == 0) { s_mv[tid >> 6] = v.v; s_mk[tid >> 6] = v.k; }
             __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < kTailThreads / 64; ++w) { const VK c = {s_mv[w], s_mk[w]}; v = comb_max(v, c); }
+            for (int w = 0; w < kTailThreads / 64; ++w) { const VK c = {s_mv[w], s_mk[w]}; v = w == 0 ? c : comb_max(v, c); }      // (every thread: the winner is uniform)
+            win[jb] = v;
+        }
+        if (ft.maxval) {            // the winners named by a value-only lane pass: their neighbours, both directions side by side
+            bool need[2]; unsigned qp[2]; long long j[2]; int tie[2]; T d2[2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) { need[jb] = jb < ft.njobs && (win[jb].k & kKeyUnresolved) && win[jb].v > -(double)Limits<T>::max_v; qp[jb] = (unsigned)(win[jb].k & 0x07ffffffll); }
+            if (need[0] || need[1]) {
+                tail_resolve2<T, NT>(ft, need, qp, j, tie, d2);
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    if (!need[jb]) continue;
+                    // (the value the lane pass certified is this minimum, or something is wrong: then the flag sends the call to the row-based path)
+                    const T val = ft.squared ? d2[jb] : (T)sqrt(d2[jb]);
+                    if ((double)val != win[jb].v) tie[jb] = 1;
+                    win[jb].k = (win[jb].k & ~0xffffffffll) | (j[jb] & 0x7fffffffll) | ((long long)tie[jb] << 31);
+                }
+            }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                if (jb >= ft.njobs) continue;
+                const VK v = win[jb];
                 const int wv = ft.w_vals + jb * (int)(sizeof(T) / 4), wi = ft.w_ij + 4 * jb, wt = ft.w_tie + jb;
                 *reinterpret_cast<T*>(&s_res[wv]) = (T)v.v; s_mask |= (sizeof(T) == 8 ? 3ull : 1ull) << wv;
                 *reinterpret_cast<long long*>(&s_res[wi]) = v.k >> 32; *reinterpret_cast<long long*>(&s_res[wi + 2]) = v.k & 0x7fffffffll; s_mask |= 15ull << wi;

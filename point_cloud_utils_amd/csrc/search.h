@@ -81,6 +81,7 @@ struct SearchArgs {
     int f_accum;                    // FUSE_ARGMAX, later wave-per-query launches of the same call (pcu_hip.hip: fused_continue): combine with the
                                     // slots instead of overwriting them
     int escalate;                   // wave-per-query passes: finish every query inside the launch (box round, then the ball round: k_search_wave)
+    int maxval;                     // fused arg-max: the lane pass runs its value-only variant (FUSE_MAXVAL; k_fuse_tail resolves the winner's neighbour)
     int brick;                      // 1: query cloud and dataset share ONE grid and the call takes search_brick.h's staged pass (fused sum, float)
     int* n_fallback;                // ... whose blocks that did not fit their stage count themselves here (pcu_hip.hip: brick feedback)
     const unsigned* cancel_word; unsigned cancel_gen;      // pcu_types.h: cancel_seen (the wave-per-query pass looks between its work items)
@@ -672,6 +673,9 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         q.x = c.v[0]; q.y = c.v[1]; q.z = c.v[2];
         q.idx = FUSE == FUSE_SUM ? 0 : a.q_idx[qpos];
     }
+    // (FUSE_MAXVAL, round 6: Hausdorff's lane pass on the fused sum's value-only program -- no winner, no tie flags, adoption -- whose partial names
+    // the arg-max QUERY; k_fuse_tail resolves that one query's neighbour, reduce.h: FuseTail::maxval)
+    constexpr bool VALUE_ONLY = FUSE == FUSE_SUM || FUSE == FUSE_MAXVAL;
     const int Gx = g.G[0], Gy = g.G[1], Gz = g.G[2];
     const int ccx = cell_of_query(g, 0, q.x), ccy = cell_of_query(g, 1, q.y), ccz = cell_of_query(g, 2, q.z);
     constexpr unsigned kRec = GE::kRec;               // bytes per record of the candidate stream
@@ -812,7 +816,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     // candidates or a few more (what the owner's shrinking minimum would have skipped), all of them dataset points of the box -- the minimum is
     // the same. Only the fused sum needs no more than the minimum (no winner's row, no tie flags); a wave whose list would not fit, or with
     // exited lanes, goes on lane by lane.
-    if (PCU_ADOPT && FUSE == FUSE_SUM) {
+    if (PCU_ADOPT && VALUE_ONLY) {
         // (list capacity: with the run list, the block's fold and 8 blocks per CU -- the occupancy the kernel is tuned for -- 160 four-byte items
         // per wave are what fits the 160 KB of LDS; an item = record index of the group (26 bits: clouds of 2^26 records or more go on lane by
         // lane) | owner lane << 26. After three own groups a wave owes ~90 groups on a uniform cloud, 140 at most in the replay.)
@@ -958,7 +962,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
                         }
                         const T m_ = min4(d_[0], d_[1], d_[2], d_[3]);
                         const bool eq_ = m_ == wbest, lt_ = m_ < wbest;
-                        if (FUSE != FUSE_SUM) { wtie2 = !lt_ && (wtie2 || (wtie && eq_)); wtie = !lt_ && (wtie || eq_); wtoff = eq_ ? off_ : wtoff; wboff = lt_ ? off_ : wboff; }
+                        if (!VALUE_ONLY) { wtie2 = !lt_ && (wtie2 || (wtie && eq_)); wtie = !lt_ && (wtie || eq_); wtoff = eq_ ? off_ : wtoff; wboff = lt_ ? off_ : wboff; }
                         wbest = lt_ ? m_ : wbest;
                     }
                 }
@@ -966,7 +970,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { const T ot = __shfl_xor(mn, o, 64); mn = ot < mn ? ot : mn; }
                 const T lb2 = face_lower_bound_inner(g, sq.x, sq.y, sq.z, bx0, bx1, by0, by1, bz0, bz1);
-                if (FUSE == FUSE_SUM) {                                       // (the sum needs the value only)
+                if (VALUE_ONLY) {                                             // (the sum / the value-only arg-max need the value only)
                     if (lane_ == l) { best = mn; lb = lb2; }
                     continue;
                 }
@@ -999,7 +1003,7 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
         if (!XYZ) return (int)reinterpret_cast<const Pt4<T>*>(base + (size_t)rec_off)->idx;
         return a.ref_idx[rec_off / kRec];
     };
-    if (FUSE != FUSE_SUM && boff != 0xffffffffu) {        // (a fused sum needs neither the row id nor the tie flags)
+    if (!VALUE_ONLY && boff != 0xffffffffu) {             // (the value-only programs need neither the row id nor the tie flags)
         int hits; unsigned ro;
         which(boff, hits, ro);
         if (ro != 0xffffffffu) bi[0] = row_id(ro);
@@ -1034,7 +1038,8 @@ __device__ __forceinline__ void search1_flat_body(const SearchArgs<T>& a, const 
     if (us >= 0 && a.ubound) a.ubound[us] = best;
     f_ok = certified;
     f_v = a.squared ? best : sqrt(best);
-    f_key = ((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u));
+    f_key = FUSE == FUSE_MAXVAL ? (((long long)q.idx << 32) | kKeyUnresolved | (long long)qpos)
+                                : (((long long)q.idx << 32) | (long long)((unsigned)bi[0] | (tie ? 0x80000000u : 0u)));
 }
 // -------------------------------------------------------------------------------------------------------
 // Main pass for k > 1 on an OPEN index (round 5): k_search's scan on the k = 1 kernel's plan. k_search walks the nine rows one after the
@@ -1257,7 +1262,7 @@ __global__ __launch_bounds__(kBlock, MINW) void k_search1_flat(const SearchArgs2
     if (FUSE == FUSE_SUM) {                     // one fp64 partial per block; lanes in a fixed order: reproducible
         const double r = block_sum(ok ? (double)v : 0.0);
         if (threadIdx.x == 0) p.a[side].f_sum[bid] = r;
-    } else if (FUSE == FUSE_ARGMAX) {           // first maximum by source row (Eigen's maxCoeff visits rows in order, strict '>')
+    } else if (FUSE == FUSE_ARGMAX || FUSE == FUSE_MAXVAL) {           // first maximum by source row (Eigen's maxCoeff visits rows in order, strict '>')
         T bv = ok ? v : -Limits<T>::max_v; long long bk = ok ? key : 0x7fffffffffffffffll;
         block_argmax(bv, bk);
         if (threadIdx.x == 0) { p.a[side].f_max_v[bid] = bv; p.a[side].f_max_k[bid] = bk; }

@@ -165,7 +165,9 @@ SWITCHES = ["PCU_HIP_TWO_PASS=1", "PCU_HIP_NO_FUSE=1", "PCU_HIP_NO_FUSED_CONTINU
             "PCU_HIP_KSEARCH_V1=1", "PCU_HIP_WAVE_ONLY_BELOW=16384", "PCU_HIP_BUCKET_MIN=32768", "PCU_HIP_NO_SIGINT=1",
             # round 6: every cloud of a two-sided call on its own grid again; the LDS-staged k = 1 pass over the shared grid (search_brick.h)
             # ... every fused call laid out from its own sample; 2048-point scatter blocks
-            "PCU_HIP_NO_SHARED_GRID=1", "PCU_HIP_BRICK=1", "PCU_HIP_NO_GEO_CACHE=1", "PCU_HIP_BUILD_PTS=2"]
+            "PCU_HIP_NO_SHARED_GRID=1", "PCU_HIP_BRICK=1", "PCU_HIP_NO_GEO_CACHE=1", "PCU_HIP_BUILD_PTS=2",
+            # ... Hausdorff's lane pass tracking every query's winner (round 5) instead of the value-only program + one resolution in the tail
+            "PCU_HIP_NO_MAXVAL=1"]
 
 
 @pytest.mark.gpu
