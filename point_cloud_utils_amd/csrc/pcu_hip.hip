@@ -541,6 +541,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
         // The layout handed down from the context's previous call (grid2.h: GridGeo): two-sided fused calls only (their *_end knows how to restart a
         // call whose layout was refused as stale). The key: everything grid_layout and the sample depend on besides the points themselves.
         static const bool geo_off = getenv("PCU_HIP_NO_GEO_CACHE") != nullptr;
+        bool geo_arm = false;
         if (keep_layout && b && !geo_off && ctx->geo.dev && a.n >= kPrepSamples && b->n >= kPrepSamples) {
             pcu_hip_ctx::GeoCache& gc = ctx->geo;
             const bool hit = gc.valid[0] && gc.valid[1] && gc.n[0] == a.n && gc.n[1] == b->n && gc.occ == occa && occa == occb && gc.h_want == a.h_want && a.h_want == b->h_want &&
@@ -550,7 +551,9 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
             s0.geo_out = g0; s1.geo_out = g1;
             if (hit) { s0.geo_in = g0; s1.geo_in = g1; }
             if (getenv("PCU_HIP_DEBUG_SKEW")) fprintf(stderr, "[layout] handed down: %d (n %d %d, shared %d)\n", (int)hit, a.n, b->n, (int)shared);
-            gc.valid[0] = gc.valid[1] = occa == occb && a.h_want == b->h_want && a.max_cells == b->max_cells;
+            // (valid again only when both launches are enqueued, below: a build that fails on the way leaves no claim on memory nobody wrote)
+            gc.valid[0] = gc.valid[1] = false;
+            geo_arm = occa == occb && a.h_want == b->h_want && a.max_cells == b->max_cells;
             gc.n[0] = a.n; gc.n[1] = b->n; gc.occ = occa; gc.h_want = a.h_want; gc.max_cells = a.max_cells; gc.shared = shared; gc.n_layout = s0.n_layout; gc.tsize = (int)sizeof(T);
         }
         const int c0 = s0.n_xpart, c1 = b ? s1.n_xpart : 0;
@@ -589,6 +592,7 @@ static int index_build_pair(GridIndex<T>& a, const T* pa, double occa, GridIndex
                     h[7], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb);
         }
         HIP_TRY(hipGetLastError());
+        if (geo_arm) ctx->geo.valid[0] = ctx->geo.valid[1] = true;       // (the sort launch's first blocks will have written this call's layout before the next call's kernels run)
         return 0;
     }
     a.lean = false; if (b) b->lean = false;            // (every other build writes the Pt4 records)
