@@ -2030,6 +2030,19 @@ static int pair_setup(pcu_hip_ctx* c, Arena& ar, hipStream_t s, const T* x, int6
             t.maxval = (fuse_mode == FUSE_ARGMAX && !maxval_off) ? 1 : 0; t.squared = squared ? 1 : 0;
             P.xy.maxval = P.yx.maxval = t.maxval != 0;
         }
+        {   // PCU_HIP_PROF_TAIL=1: stage timers of k_fuse_tail, printed every 256 calls (diagnostics)
+            static const bool prof_tail = getenv("PCU_HIP_PROF_TAIL") != nullptr;
+            static long long* tail_prof = nullptr; static long n_tail = 0;
+            if (prof_tail) {
+                if (!tail_prof) { HIP_TRY(hipMalloc((void**)&tail_prof, 8 * sizeof(long long))); HIP_TRY(hipMemset(tail_prof, 0, 8 * sizeof(long long))); }
+                if (++n_tail % 256 == 0) {
+                    long long h[8]; HIP_TRY(hipMemcpy(h, tail_prof, sizeof h, hipMemcpyDeviceToHost)); HIP_TRY(hipMemset(tail_prof, 0, sizeof h));
+                    const double nb = h[7] > 0 ? (double)h[7] * 100.0 : 100.0;
+                    fprintf(stderr, "[fuse_tail prof] calls %lld | mean us: partials %.2f  winners %.2f  resolve %.2f  finish %.2f\n", h[7], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb);
+                }
+                t.prof = tail_prof;
+            }
+        }
         t.result_block = reinterpret_cast<const int*>(P.rb); t.host_block = c->h_pinned; t.seq = ++c->seq;
         t.w_sums = (int)(offsetof(ResultBlock, sums) / 4); t.w_vals = (int)(offsetof(ResultBlock, vals) / 4);
         t.w_ij = (int)(offsetof(ResultBlock, ij) / 4); t.w_tie = (int)(offsetof(ResultBlock, pad) / 4) + 2;

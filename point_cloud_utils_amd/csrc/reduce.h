@@ -137,6 +137,7 @@ struct FuseTail {
     // pass certified its value inside the 27, or inside these by its radius-2 rescue) in the distance's own arithmetic, takes the minimum, and
     // reports the dataset row -- or, if two records share the minimum, the tie flag, which sends the call to the row-based path as before.
     int maxval, squared;
+    long long* prof;                             // diagnostics (PCU_HIP_PROF_TAIL): stage times of thread 0, summed over calls; 100 MHz ticks; [7] = calls
     const GridParams<T>* r_gp[2]; const unsigned* r_cs[2]; const T* r_xyz[2]; const int* r_idx[2]; const T* q_xyz[2];
 };
 
@@ -148,9 +149,13 @@ template <typename T, int NT>
 __device__ __forceinline__ void tail_resolve2(const FuseTail<T>& ft, const bool (&need)[2], const unsigned (&qpos)[2], long long (&j_out)[2], int (&tie_out)[2], T (&min_d2)[2]) {
     constexpr int H = NT / 2, HW = H / 64;
     static_assert(H / 16 >= 25, "a row of the box per 16 threads");
-    __shared__ T s_d[NT / 64]; __shared__ unsigned s_pos[NT / 64], s_cnt[NT / 64];
+    __shared__ T s_d[NT / 64]; __shared__ unsigned s_pos[NT / 64], s_cnt[NT / 64]; __shared__ int s_row[NT / 64];
     const int tid = threadIdx.x, d = tid >= H ? 1 : 0, lt = tid - d * H;
-    T best = Limits<T>::max_v; unsigned pos = 0xffffffffu, cnt = 0;
+    T best = Limits<T>::max_v; unsigned pos = 0xffffffffu, cnt = 0; int row = 0x7fffffff;      // (row: the dataset row of `pos`, fetched with the record -- not a round trip of its own at the end)
+    auto take = [&](T d2, unsigned p2, unsigned c2, int r2) {
+        if (d2 < best) { best = d2; pos = p2; cnt = c2; row = r2; }
+        else if (d2 == best) { cnt += c2; if (p2 < pos) { pos = p2; row = r2; } }
+    };
     if (need[d]) {
         const GridParams<T>& g = *ft.r_gp[d];
         const T* const qp = ft.q_xyz[d] + 3 * (size_t)qpos[d];
@@ -163,32 +168,27 @@ __device__ __forceinline__ void tail_resolve2(const FuseTail<T>& ft, const bool 
         if (r < nrows) {
             const unsigned lo = (unsigned)row_run_lo(Gx, grid_row(Gy, by0 + r % ny, bz0 + r / ny), bx0, bx1);
             const unsigned s = ft.r_cs[d][lo], e = ft.r_cs[d][lo + (unsigned)(bx1 - bx0 + 1)];
-            const T* const xyz = ft.r_xyz[d];
+            const T* const xyz = ft.r_xyz[d]; const int* const rid = ft.r_idx[d];
             for (unsigned i = s + (unsigned)sl; i < e; i += 16u) {
+                const int ri = rid[i];
                 const T dx = qx - xyz[3 * (size_t)i], dy = qy - xyz[3 * (size_t)i + 1], dz = qz - xyz[3 * (size_t)i + 2];
-                const T dd = ((dx * dx) + (dy * dy)) + (dz * dz);         // (the distance's own arithmetic: nanoflann.hpp:496-507)
-                if (dd < best) { best = dd; pos = i; cnt = 1; } else if (dd == best) { ++cnt; pos = i < pos ? i : pos; }
+                take(((dx * dx) + (dy * dy)) + (dz * dz), i, 1u, ri);         // (the distance's own arithmetic: nanoflann.hpp:496-507)
             }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {          // (a wave belongs to one direction: H is a multiple of 64)
-        const T d2 = __shfl_xor(best, o, 64); const unsigned p2 = (unsigned)__shfl_xor((int)pos, o, 64), c2 = (unsigned)__shfl_xor((int)cnt, o, 64);
-        if (d2 < best) { best = d2; pos = p2; cnt = c2; } else if (d2 == best) { cnt += c2; pos = p2 < pos ? p2 : pos; }
-    }
+    for (int o = 32; o > 0; o >>= 1)            // (a wave belongs to one direction: H is a multiple of 64)
+        take(__shfl_xor(best, o, 64), (unsigned)__shfl_xor((int)pos, o, 64), (unsigned)__shfl_xor((int)cnt, o, 64), __shfl_xor(row, o, 64));
     __syncthreads();
-    if ((tid & 63) == 0) { s_d[tid >> 6] = best; s_pos[tid >> 6] = pos; s_cnt[tid >> 6] = cnt; }
+    if ((tid & 63) == 0) { s_d[tid >> 6] = best; s_pos[tid >> 6] = pos; s_cnt[tid >> 6] = cnt; s_row[tid >> 6] = row; }
     __syncthreads();
 #pragma unroll
     for (int dd_ = 0; dd_ < 2; ++dd_) {
-        T bd = s_d[dd_ * HW]; unsigned bp = s_pos[dd_ * HW], bc = s_cnt[dd_ * HW];
-        for (int w = 1; w < HW; ++w) {
-            const T d2 = s_d[dd_ * HW + w]; const unsigned p2 = s_pos[dd_ * HW + w], c2 = s_cnt[dd_ * HW + w];
-            if (d2 < bd) { bd = d2; bp = p2; bc = c2; } else if (d2 == bd) { bc += c2; bp = p2 < bp ? p2 : bp; }
-        }
-        min_d2[dd_] = bd;
-        j_out[dd_] = (need[dd_] && bp != 0xffffffffu) ? (long long)ft.r_idx[dd_][bp] : 0x7fffffffll;
-        tie_out[dd_] = (bc > 1u || bp == 0xffffffffu) ? 1 : 0;
+        best = s_d[dd_ * HW]; pos = s_pos[dd_ * HW]; cnt = s_cnt[dd_ * HW]; row = s_row[dd_ * HW];
+        for (int w = 1; w < HW; ++w) take(s_d[dd_ * HW + w], s_pos[dd_ * HW + w], s_cnt[dd_ * HW + w], s_row[dd_ * HW + w]);
+        min_d2[dd_] = best;
+        j_out[dd_] = (need[dd_] && pos != 0xffffffffu) ? (long long)row : 0x7fffffffll;
+        tie_out[dd_] = (cnt > 1u || pos == 0xffffffffu) ? 1 : 0;
     }
 }
 
@@ -234,6 +234,8 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     __shared__ int s_res[64]; __shared__ unsigned long long s_mask;
     constexpr int kTailThreads = NT, V = kTailLanes / NT;
     const int tid = threadIdx.x;
+    long long t_prev = ft.prof ? wall_clock64() : 0;
+#define TAIL_PROF(slot) do { if (ft.prof && tid == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&ft.prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
     double acc[2][V];
 #pragma unroll
     for (int q = 0; q < V; ++q) { acc[0][q] = 0; acc[1][q] = 0; }
@@ -284,6 +286,7 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
             }
         }
     }
+    TAIL_PROF(0);                                   // partials in, combined per thread
     const int rbw = tid < 63 ? ft.result_block[tid] : 0;
     if (tid == 0) s_mask = 0ull;
     if (ft.mode == FUSE_SUM) {
@@ -294,19 +297,33 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
             if (tid == 0) { *reinterpret_cast<double*>(&s_res[ft.w_sums + 2 * jb]) = r; s_mask |= 3ull << (ft.w_sums + 2 * jb); }
         }
     } else {
+        // block winners of both directions in ONE pair of barriers (stage timers, PCU_HIP_PROF_TAIL: per direction a wave butterfly, two barriers and a
+        // serial walk over the 16 wave winners in LDS took 7.5 us of the tail's 15.7): wave butterflies for both, one exchange through LDS, then wave 0's
+        // lanes 0..15 / 16..31 fold the 16 wave winners of direction 0 / 1 by a 4-step butterfly and publish them
         VK win[2] = {best[0], best[1]};
+        __shared__ double s_wv[2][NT / 64]; __shared__ long long s_wk[2][NT / 64]; __shared__ double s_fv[2]; __shared__ long long s_fk[2];
+        static_assert(NT / 64 == 16, "16 wave winners per direction");
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-            if (jb >= ft.njobs) continue;
-            VK v = best[jb];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = comb_max(v, shfl_vk(v, o));
-            __syncthreads();
-            if ((tid & 63) == 0) { s_mv[tid >> 6] = v.v; s_mk[tid >> 6] = v.k; }
-            __syncthreads();
-            for (int w = 0; w < kTailThreads / 64; ++w) { const VK c = {s_mv[w], s_mk[w]}; v = w == 0 ? c : comb_max(v, c); }      // (every thread: the winner is uniform)
-            win[jb] = v;
+            for (int o = 32; o > 0; o >>= 1) win[jb] = comb_max(win[jb], shfl_vk(win[jb], o));
         }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) { s_wv[jb][tid >> 6] = win[jb].v; s_wk[jb][tid >> 6] = win[jb].k; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int jb = tid >> 4, w = tid & 15;
+            VK v = {s_wv[jb][w], s_wk[jb][w]};
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v = comb_max(v, shfl_vk(v, o));
+            if (w == 0) { s_fv[jb] = v.v; s_fk[jb] = v.k; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) { win[jb].v = s_fv[jb]; win[jb].k = s_fk[jb]; }
+        TAIL_PROF(1);                               // block winners
         if (ft.maxval) {            // the winners named by a value-only lane pass: their neighbours, both directions side by side
             bool need[2]; unsigned qp[2]; long long j[2]; int tie[2]; T d2[2];
 #pragma unroll
@@ -323,6 +340,7 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
                 }
             }
         }
+        TAIL_PROF(2);                               // winners' neighbours resolved
         if (tid == 0) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
@@ -336,6 +354,9 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
         }
     }
     __syncthreads();
+    TAIL_PROF(3);                                   // sums / result words ready
+    if (ft.prof && tid == 0) atomicAdd((unsigned long long*)&ft.prof[7], 1ull);
+#undef TAIL_PROF
     if (tid < 64) {
         if (tid < 63) ft.host_block[tid] = ((s_mask >> tid) & 1ull) ? s_res[tid] : rbw;
         __threadfence_system();
