@@ -236,6 +236,7 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     const int tid = threadIdx.x;
     long long t_prev = ft.prof ? wall_clock64() : 0;
 #define TAIL_PROF(slot) do { if (ft.prof && tid == 0) { const long long t_now = wall_clock64(); atomicAdd((unsigned long long*)&ft.prof[slot], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
+    const int rbw = tid < 63 ? ft.result_block[tid] : 0;       // (requested with the partials: a round trip of its own when it was asked for after them)
     double acc[2][V];
 #pragma unroll
     for (int q = 0; q < V; ++q) { acc[0][q] = 0; acc[1][q] = 0; }
@@ -287,7 +288,6 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
         }
     }
     TAIL_PROF(0);                                   // partials in, combined per thread
-    const int rbw = tid < 63 ? ft.result_block[tid] : 0;
     if (tid == 0) s_mask = 0ull;
     if (ft.mode == FUSE_SUM) {
 #pragma unroll
