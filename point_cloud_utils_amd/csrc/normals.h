@@ -99,12 +99,16 @@ __global__ __launch_bounds__(kBlock) void k_normals_knn(const NormalsKnnArgs<T> 
     bool ok = row[a.k - 1] >= 0;       // founds < num_neighbors: the point is discarded (:143-146)
     if (ok) {
         struct __attribute__((packed, aligned(4))) P3 { T v[3]; };      // a neighbour = ONE 12 / 24-byte gather (three scalar loads cost the vector-memory path three instructions)
-        for (int j = 0; j < a.k; ++j) {
-            const long long r = row[j];
+        // (a thread's row of k int64 ids lies k * 8 bytes from its neighbour's: every load of it is a per-lane gather, so the ids come two per 16-byte load)
+        struct __attribute__((packed, aligned(8))) Id2 { long long v[2]; };
+        auto add = [&](long long r) {
             const P3 nb = *reinterpret_cast<const P3*>(a.pts + 3 * r);
             const double ox = (double)(T)(nb.v[0] - qx), oy = (double)(T)(nb.v[1] - qy), oz = (double)(T)(nb.v[2] - qz);
             S.xx += ox * ox; S.xy += ox * oy; S.xz += ox * oz; S.yy += oy * oy; S.yz += oy * oz; S.zz += oz * oz;
-        }
+        };
+        int j = 0;
+        for (; j + 1 < a.k; j += 2) { const Id2 p = *reinterpret_cast<const Id2*>(row + j); add(p.v[0]); add(p.v[1]); }       // (the reference's order: ascending distance)
+        if (j < a.k) add(row[j]);
     }
     double nx = 0, ny = 0, nz = 0;
     if (ok) {
