@@ -289,7 +289,28 @@ __device__ __forceinline__ void fuse_tail_body(const FuseTail<T>& ft) {
     }
     TAIL_PROF(0);                                   // partials in, combined per thread
     if (tid == 0) s_mask = 0ull;
-    if (ft.mode == FUSE_SUM) {
+    if (ft.mode == FUSE_SUM && V == 1) {
+        // tail_sum's order (butterfly inside a wave, the 16 wave sums added in order) for both directions behind ONE pair of barriers
+        __shared__ double s_ws[2][kTailLanes / 64];
+        double w[2] = {acc[0][0], acc[1][0]};
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w[jb] += __shfl_xor(w[jb], o, 64);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { s_ws[0][tid >> 6] = w[0]; s_ws[1][tid >> 6] = w[1]; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                if (jb >= ft.njobs) continue;
+                double r = s_ws[jb][0];
+                for (int i = 1; i < kTailLanes / 64; ++i) r += s_ws[jb][i];
+                *reinterpret_cast<double*>(&s_res[ft.w_sums + 2 * jb]) = r; s_mask |= 3ull << (ft.w_sums + 2 * jb);
+            }
+        }
+    } else if (ft.mode == FUSE_SUM) {
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
             if (jb >= ft.njobs) continue;
